@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors for the GP-emission hot path by RUNNING THE REFERENCE.
+
+Build-container only: imports the read-only reference at /root/reference (never copied), with
+in-memory stand-ins for the four third-party packages that are absent here (gpytorch,
+torchmetrics, pyro, wfdb) and with kernel hyper-parameters injected in place of the gpytorch fit
+ - every vector is taken downstream of that injection.
+
+Usage (from the repo root):   python tests/golden/make_golden.py
+Writes tests/golden/*.npz - data only (inputs + the reference's outputs, fp64).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/hdpgpc"
+OUT = os.path.dirname(os.path.abspath(__file__))
+THETA_INJECT = (341.0, 1.2, 4.66)  # outputscale, lengthscale (GPI.py:711 forces 1.2), noise before clamping
+
+
+def _register_standins():
+    def _mod(n):
+        m = types.ModuleType(n)
+        sys.modules[n] = m
+        return m
+
+    g = _mod("gpytorch")
+    for s in ["models", "variational", "means", "kernels", "likelihoods", "constraints", "mlls",
+              "distributions", "settings"]:
+        setattr(g, s, _mod("gpytorch." + s))
+
+    class _B(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    g.models.ExactGP = g.models.ApproximateGP = g.means.Mean = _B
+    g.variational.CholeskyVariationalDistribution = g.variational.VariationalStrategy = _B
+    tm = _mod("torchmetrics")
+    tm.audio = _mod("torchmetrics.audio")
+
+    class SignalNoiseRatio:  # torchmetrics.functional.audio.signal_noise_ratio, zero_mean=False
+        def __call__(self, preds, target):
+            eps = torch.finfo(preds.dtype).eps
+            noise = target - preds
+            return 10 * torch.log10((torch.sum(target ** 2, -1) + eps) / (torch.sum(noise ** 2, -1) + eps))
+
+    tm.audio.SignalNoiseRatio = SignalNoiseRatio
+    p = _mod("pyro")
+    p.contrib = _mod("pyro.contrib")
+    p.contrib.gp = _mod("pyro.contrib.gp")
+    p.distributions = _mod("pyro.distributions")
+    w = _mod("wfdb")
+    w.processing = _mod("wfdb.processing")
+
+
+_register_standins()
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+import hdpgpc.GPI as GPI  # noqa: E402
+import hdpgpc.GPI_model as GM  # noqa: E402
+import hdpgpc.GPI_HDP as HDP  # noqa: E402
+from hdpgpc.get_data import compute_estimators_LDS  # noqa: E402
+from hdpgpc.amtgp_warping_system import WarpPriorAMTGP  # noqa: E402
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel, WhiteKernel  # noqa: E402
+
+
+def _fit_torch_fixed(self, x, y, alpha_ini, gamma_ini, reduced_points=False, verbose=False):
+    """Harness-only replacement of the gpytorch fit: inject fixed theta."""
+    if not self.fitted:
+        k = self.kernel
+        k.k1.k1.theta = np.log([THETA_INJECT[0]])
+        k.k1.k2.theta = np.log([THETA_INJECT[1]])
+        lo, hi = k.k2.noise_level_bounds
+        k.k2.theta = np.log([min(max(THETA_INJECT[2], lo), hi)])
+        x_ = self.cond_to_numpy(self.x_basis)
+        self.K_X_X = self.cond_to_torch(self.kernel(x_, x_))
+        self.K_inv = self.inv_r("kernelMat", self.K_X_X)
+        self.fitted = True
+        eye = torch.eye(self.x_basis.shape[0])
+        self.assign_alpha_ini(torch.mul(self.cond_to_torch(k.k2.noise_level), eye),
+                              torch.mul(self.cond_to_torch(gamma_ini), eye))
+    return self.fitted
+
+
+GPI.IterativeGaussianProcess.fit_torch = _fit_torch_fixed
+torch.set_default_dtype(torch.float64)
+
+
+def npy(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def kernel_theta(k):
+    return np.array([k.k1.k1.constant_value, k.k1.k2.length_scale, k.k2.noise_level], dtype=np.float64)
+
+
+def make_kernel(c, ell, noise, nb=(1e-10, 1e10)):
+    return ConstantKernel(c, (c, c * 5.0)) * RBF(ell, (1.0, 20.0)) + WhiteKernel(noise, nb)
+
+
+# ----------------------------------------------------------------------------- a1
+def gen_gram():
+    rng = np.random.default_rng(1)
+    out = {}
+    cases = [(8, 8, 2.5, 1.2, 0.3), (33, 20, 341.0, 1.2, 0.9), (90, 178, 300.0, 3.0, 1e-3), (128, 128, 17.0, 0.7, 2.0)]
+    for i, (n, m, c, ell, noise) in enumerate(cases):
+        k = make_kernel(c, ell, noise)
+        X = (np.arange(n) + rng.uniform(-0.3, 0.3, n))[:, None]
+        Y = (np.linspace(0, n - 1, m) + rng.uniform(-0.2, 0.2, m))[:, None]
+        out[f"c{i}_theta"] = np.array([c, ell, noise])
+        out[f"c{i}_X"] = X[:, 0]
+        out[f"c{i}_Y"] = Y[:, 0]
+        out[f"c{i}_K_one"] = k(X)          # one-argument call: white noise on the diagonal
+        out[f"c{i}_K_two"] = k(X, Y)       # two-argument call: no white noise
+        out[f"c{i}_K_self"] = k(X, X)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "gram.npz"), **out)
+
+
+# ------------------------------------------------------------------------ a3, a4
+def gen_score_shared():
+    rng = np.random.default_rng(2)
+    xb = np.arange(8.0)[:, None]
+    gm = GM.GPI_model(make_kernel(1.0, 1.0, 0.1), xb, verbose=False)
+    out = {}
+    i = 0
+    for T in (8, 33, 90, 128):
+        for B in (1, 7, 64):
+            for kind in ("iso", "dense"):
+                if kind == "iso":
+                    cov = 2.3 * np.eye(T)
+                else:
+                    Q = rng.normal(size=(T, T))
+                    cov = Q @ Q.T / T + np.diag(rng.uniform(0.5, 2.0, T))
+                    cov = cov + 1e-3 * rng.normal(size=(T, T))  # slightly non-symmetric on purpose (a3 symmetrises)
+                mean = rng.normal(size=(T, 1)) * 10
+                Y = rng.normal(size=(B, T, 1)) * 3 + mean[None]
+                sc = gm._gaussian_score_shared_cov(torch.from_numpy(Y), torch.from_numpy(mean), torch.from_numpy(cov))
+                L = gm._chol_spd(torch.from_numpy(cov))
+                out[f"c{i}_cov"], out[f"c{i}_mean"], out[f"c{i}_Y"] = cov, mean[:, 0], Y[..., 0]
+                out[f"c{i}_score"], out[f"c{i}_L"] = npy(sc), npy(L)
+                i += 1
+    out["n_cases"] = np.array(i)
+    np.savez_compressed(os.path.join(OUT, "score_shared.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- a2
+def gen_pred_dist():
+    rng = np.random.default_rng(3)
+    out = {}
+    i = 0
+    for (T, Ts, c, ell, noise) in [(8, 8, 5.0, 1.2, 0.5), (33, 33, 341.0, 1.2, 0.9), (33, 50, 341.0, 1.2, 0.9),
+                                   (90, 178, 341.0, 1.2, 0.9), (128, 128, 358.05, 1.2, 0.9), (48, 48, 100.0, 3.0, 0.2)]:
+        xb = np.arange(float(T))[:, None]
+        gp = GPI.IterativeGaussianProcess(make_kernel(c, ell, noise), xb, verbose=False)
+        if Ts == T:
+            xp = xb + rng.uniform(-0.3, 0.3, (T, 1))
+        else:
+            xp = np.linspace(0, T - 1, Ts)[:, None]
+        for kind in ("dense", "iso"):
+            if kind == "iso":
+                Sig = 1.7 * np.eye(T)
+            else:
+                v = rng.normal(size=T)
+                Sig = rng.uniform(0.5, 5.0) * (np.eye(T) + 0.1 * np.outer(v, v))
+            mean = 50 * np.exp(-0.5 * ((xb - T / 2) / (0.1 * T)) ** 2) + rng.normal(size=(T, 1))
+            f, cov = gp.pred_dist(torch.from_numpy(xp), torch.from_numpy(xb), torch.from_numpy(mean), torch.from_numpy(Sig))
+            fl, covl = gp.pred_latent_dist(torch.from_numpy(xp), torch.from_numpy(xb), torch.from_numpy(mean),
+                                           torch.from_numpy(Sig))
+            out[f"c{i}_theta"] = np.array([c, ell, noise])
+            out[f"c{i}_xb"], out[f"c{i}_xp"], out[f"c{i}_mean"], out[f"c{i}_Sigma"] = xb[:, 0], xp[:, 0], mean[:, 0], Sig
+            out[f"c{i}_f"], out[f"c{i}_cov"] = npy(f)[:, 0], npy(cov)
+            out[f"c{i}_f_lat"], out[f"c{i}_cov_lat"] = npy(fl)[:, 0], npy(covl)
+            i += 1
+    out["n_cases"] = np.array(i)
+    np.savez_compressed(os.path.join(OUT, "pred_dist.npz"), **out)
+
+
+# --------------------------------------------------------- a5-a9 on a real LDS state
+def load_beats(rec, n, stride=1, lead=0):
+    d = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:n, ::stride, [lead]]
+    return np.ascontiguousarray(d)
+
+
+def build_model(data, members, free_deg=5):
+    """One GPI_model driven through the reference's own full_pass_weighted on ``members``."""
+    N, T, _ = data.shape
+    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data)
+    xb = np.arange(float(T))[:, None]
+    kern = ConstantKernel(300.0, (300.0, 1500.0)) * RBF(3.0, (1.0, 20.0)) + WhiteKernel(bound_sigma[0], bound_sigma)
+    gm = GM.GPI_model(kern, xb, annealing=True, bayesian=True, free_deg_MNIV=free_deg, verbose=False)
+    cond = gm.GPR_dynamic(std_dif, std)
+    gm.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
+    x_trains = torch.from_numpy(np.array([xb] * N))
+    y_trains = torch.from_numpy(data)
+    resp = torch.zeros(N)
+    resp[list(members)] = 1.0
+    q, q_lat = gm.full_pass_weighted(x_trains, y_trains, resp)
+    return gm, x_trains, y_trains, q, q_lat
+
+
+def dump_state(gm, prefix, out):
+    out[prefix + "theta"] = kernel_theta(gm.gp.kernel)
+    out[prefix + "x_basis"] = npy(gm.x_basis)[:, 0]
+    out[prefix + "indexes"] = np.array(gm.indexes, dtype=np.int64)
+    for name in ("f_star", "f_star_sm"):
+        out[prefix + name] = np.stack([npy(f).reshape(-1) for f in getattr(gm, name)])
+    for name in ("cov_f_sm", "A", "Gamma", "C", "Sigma"):
+        out[prefix + name] = np.stack([npy(m) for m in getattr(gm, name)])
+    for name in ("A_def", "Gamma_def", "C_def", "Sigma_def"):
+        out[prefix + name] = npy(getattr(gm, name))
+    out[prefix + "n0"] = np.array(float(gm.internal_params.n0))
+
+
+def gen_state(tag, rec, n, stride, members, seed):
+    rng = np.random.default_rng(seed)
+    data = load_beats(rec, n, stride)
+    gm, x_trains, y_trains, q, q_lat = build_model(data, members)
+    T = data.shape[1]
+    out = {"y": data[..., 0]}
+    dump_state(gm, "st_", out)
+    out["q_shared"] = npy(q)
+    out["q_lat"] = npy(q_lat)
+    out["q_shared_nofirst"] = npy(gm.compute_sq_err_all(x_trains, y_trains, no_first=True))
+    # irregular grids: per-segment general path (3 Gram builds + 2 Cholesky per evaluation)
+    x_irr = np.arange(float(T))[None, :, None] + rng.uniform(-0.3, 0.3, (n, T, 1))
+    out["x_irr"] = x_irr[..., 0]
+    out["q_irr"] = npy(gm.compute_sq_err_all(torch.from_numpy(x_irr), y_trains))
+    # online-style calls against the last state (i=-1) and with explicit params / first
+    out["lse_last"] = np.array([float(gm.log_sq_error(torch.from_numpy(x_irr[j]), y_trains[j], i=-1)) for j in range(n)])
+    out["lse_last_shared"] = np.array([float(gm.log_sq_error(x_trains[j], y_trains[j], i=-1)) for j in range(n)])
+    out["lse_none"] = np.array([float(gm.log_sq_error(torch.from_numpy(x_irr[j]), y_trains[j])) for j in range(n)])
+    pm, pc, pC, pS = gm.f_star_sm[-2], gm.cov_f_sm[-2], gm.C[-2], gm.Sigma[-2]
+    out["lse_params_first"] = np.array([float(gm.log_sq_error(torch.from_numpy(x_irr[j]), y_trains[j], mean=pm, cov=pc,
+                                                              C=pC, Sigma=pS, i=0, first=True)) for j in range(n)])
+    out["lds_lik"] = np.array(float(gm.return_LDS_param_likelihood()))
+    out["lds_lik_first"] = np.array(float(gm.return_LDS_param_likelihood(first=True)))
+    # raw MNIW terms
+    ip = GM.matrix_normal_inv_wishart(gm.C_def, torch.eye(T), gm.free_deg_MNIV, gm.Sigma_def)
+    out["mniw_obs"] = np.array(float(ip.log_likelihood_MNIW(gm.C[-1], gm.Sigma[-1], gm.internal_params.n0)))
+    # observe_last on a denser grid (util_plots.py:755-758 does this with step 0.5)
+    xd = np.arange(0, T - 1 + 1e-9, 0.5)[:, None]
+    f, cov = gm.observe_last(torch.from_numpy(xd))
+    out["x_dense"], out["obs_last_f"], out["obs_last_cov"] = xd[:, 0], npy(f)[:, 0], npy(cov)
+    np.savez_compressed(os.path.join(OUT, f"state_{tag}.npz"), **out)
+    print(f"state_{tag}: T={T} members={list(members)} q_irr[:3]={out['q_irr'][:3]}")
+
+
+# ---------------------------------------------------------------------------- a10
+def gen_lml():
+    rng = np.random.default_rng(5)
+    out = {}
+    for i, (T, c, ell, noise) in enumerate([(16, 3.0, 1.5, 0.2), (60, 341.0, 1.2, 0.9), (90, 300.0, 3.0, 0.5)]):
+        xb = np.arange(float(T))[:, None]
+        k = make_kernel(c, ell, noise)
+        gp = GPI.IterativeGaussianProcess(k, xb, verbose=False)
+        y = np.sin(xb / 5.0) * 10 + rng.normal(size=(T, 1))
+        val = gp.log_marginal_likelihood(torch.from_numpy(xb), torch.from_numpy(y), None, theta=k.theta)
+        out[f"c{i}_theta"], out[f"c{i}_x"], out[f"c{i}_y"] = np.array([c, ell, noise]), xb[:, 0], y[:, 0]
+        out[f"c{i}_lml"] = np.array(float(np.asarray(val).reshape(-1)[0]))
+    out["n_cases"] = np.array(3)
+    np.savez_compressed(os.path.join(OUT, "lml.npz"), **out)
+
+
+# ---------------------------------------------------------------------------- a11
+def gen_warp_prior():
+    rng = np.random.default_rng(6)
+    out = {}
+    i = 0
+    for (T, B, rho, omega, noise) in [(16, 5, 0.3, 1.0, 0.05), (45, 128, 0.2, 2.0, 0.01), (90, 33, 0.5, 0.7, 0.1)]:
+        x = np.arange(float(T)) * 2.0
+        wp = WarpPriorAMTGP(noise_warp=noise, bound_noise_warp=(1e-10, 1e10))
+        wp.theta = (rho, omega)
+        W = x[None, :] + rng.normal(size=(B, T)) * 0.3
+        val = wp.log_sq_error_batch(torch.from_numpy(x), torch.from_numpy(W))
+        one = wp.log_sq_error(torch.from_numpy(x), torch.from_numpy(W[0]))
+        r, o = wp._parse_theta()
+        out[f"c{i}_x"], out[f"c{i}_W"] = x, W
+        out[f"c{i}_par"] = np.array([r, o, float(wp._clamped_noise("cpu", torch.float64)), wp.jitter, float(wp.normalize_x)])
+        out[f"c{i}_val"], out[f"c{i}_one"] = npy(val), np.array(float(one))
+        i += 1
+    out["n_cases"] = np.array(i)
+    np.savez_compressed(os.path.join(OUT, "warp_prior.npz"), **out)
+
+
+# -------------------------------------------------- end-to-end: offline include_batch
+def gen_offline(tag, rec, n, stride):
+    data = load_beats(rec, n, stride)
+    N, T, _ = data.shape
+    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data)
+    xb = np.arange(float(T))[:, None]
+    x_trains = np.array([xb] * N)
+    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic",
+                     ini_lengthscale=3.0, bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std,
+                     ini_outputscale=300.0, noise_warp=std * 0.1, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
+                     bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False, method_compute_warp="greedy",
+                     verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
+                     inducing_points=False, reestimate_initial_params=True, n_explore_steps=5, free_deg_MNIV=5)
+    sw.include_batch(x_trains, data, warp=False)
+    xt, yt = torch.from_numpy(x_trains), torch.from_numpy(data)
+    models = [g for g in sw.gpmodels[0] if len(g.indexes) > 0]
+    out = {"y": data[..., 0], "x_basis": xb[:, 0], "M": np.array(len(models)),
+           "resp_assigned": npy(sw.resp_assigned[-1]).astype(np.int64)}
+    qs = []
+    for m, g in enumerate(models):
+        q = g.compute_sq_err_all(xt, yt)
+        qs.append(npy(q))
+        # per-step observation state actually read by compute_sq_err_all: mean_i = C_i f_i , Sigma_i
+        S = len(g.f_star)
+        means = np.stack([npy(torch.matmul(g.C[min(i, len(g.C) - 1)], g.f_star[i])).reshape(-1) for i in range(S)])
+        out[f"m{m}_means"] = means
+        out[f"m{m}_Sigma"] = np.stack([npy(s) for s in g.Sigma])
+        out[f"m{m}_indexes"] = np.array(g.indexes, dtype=np.int64)
+        out[f"m{m}_theta"] = kernel_theta(g.gp.kernel)
+        out[f"m{m}_q_lat"] = npy(g.compute_q_lat_all(xt))
+    out["q"] = np.stack(qs, axis=1)
+    np.savez_compressed(os.path.join(OUT, f"offline_{tag}.npz"), **out)
+    print(f"offline_{tag}: N={N} T={T} M={len(models)} counts={[len(g.indexes) for g in models]}")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gram", "score", "pred", "state", "lml", "warp", "offline"]
+    if "gram" in which:
+        gen_gram()
+    if "score" in which:
+        gen_score_shared()
+    if "pred" in which:
+        gen_pred_dist()
+    if "state" in which:
+        gen_state("t30", "100", 14, 3, [2, 5, 6, 9, 12], 11)
+        gen_state("t45", "102", 24, 2, [0, 1, 2, 3, 4, 7, 8, 11, 15, 16, 20], 12)
+        gen_state("t90", "100", 8, 1, [0, 1, 3, 6], 13)
+    if "lml" in which:
+        gen_lml()
+    if "warp" in which:
+        gen_warp_prior()
+    if "offline" in which:
+        gen_offline("r102_t45", "102", 60, 2)
+    print("done")
