@@ -1,0 +1,54 @@
+"""ctypes binding of libhdpgpc_hip.so (include/hdpgpc_hip.h).
+
+The product path has no CPU fallback: importing this module without the built library raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhdpgpc_hip.so")
+
+c_dp = ctypes.c_void_p  # device pointers travel as integers
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). hdpgpc_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    i32, i64, f64, vp, sz = ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+    sigs = {
+        "hgp_abi_version": (i32, []),
+        "hgp_debug_mfma_f64": (i32, [vp, vp, vp, vp]),
+        "hgp_gram_rbf_f64": (i32, [vp, i32, vp, i32, f64, f64, f64, vp, vp]),
+        "hgp_potrf_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, vp]),
+        "hgp_score_groups_f64": (i32, [vp, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i32, vp, f64, vp, vp, vp, vp]),
+        "hgp_pairs_plan_device_bytes": (sz, [i32, i32, i32]),
+        "hgp_pairs_plan_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, ctypes.POINTER(f64), vp, sz]),
+        "hgp_pairs_plan_destroy": (None, [vp]),
+        "hgp_pairs_plan_update": (i32, [vp, vp, vp, vp, vp, vp]),
+        "hgp_loglik_pairs_f64": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sigs)
+
+
+lib, EXPORTS = _load()
+
+
+class HgpError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise ValueError(f"{what}: bad argument")
+    if rc == -2:
+        raise NotImplementedError(f"{what}: size not supported by this build")
+    raise HgpError(f"{what}: HIP error {rc - 1000}")

@@ -1,0 +1,775 @@
+// libhdpgpc_hip.so - HIP kernels (gfx950) and the C-ABI of include/hdpgpc_hip.h.
+// One wavefront owns one SPD matrix (<= 128 x 128) in MFMA accumulator registers; see tile_f64.hpp.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/hdpgpc_hip.h"
+#include "tile_f64.hpp"
+
+using namespace hgp;
+
+namespace {
+
+constexpr int WAVES = 4;  // waves per workgroup: one per SIMD of a CU
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : 1000 + (int)e;
+}
+
+inline int nb_for(int n) {  // tile count, rounded to the instantiated sizes {2,4,6,8}
+  int nb = (n + 15) / 16;
+  nb = (nb + 1) & ~1;
+  return nb < 2 ? 2 : nb;
+}
+
+// ------------------------------------------------------------------------------------------ a1
+__global__ void k_gram_rbf(const double* __restrict__ x, int nx, const double* __restrict__ y, int ny, double c,
+                           double ell, double noise, int one_arg, double* __restrict__ K) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)nx * ny) return;
+  int i = (int)(idx / ny), j = (int)(idx % ny);
+  double u = x[i] / ell - (one_arg ? x[j] : y[j]) / ell;   // sklearn divides by the length-scale first
+  double v = c * exp(-0.5 * (u * u));
+  if (one_arg && i == j) v = c + noise;
+  K[idx] = v;
+}
+
+// diagnostics: one 16x16x16 product through the operand / accumulator lane maps tile_f64.hpp assumes
+__global__ void k_mfma_probe(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = mfma(A[c * 16 + 4 * s + g], B[(4 * s + g) * 16 + c], acc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) C[(g + 4 * r) * 16 + c] = acc[r];
+}
+
+// ------------------------------------------------------------------------------------------ a3
+struct PotrfArgs {
+  double* A;
+  int T, b;
+  double jitter_rel, add;
+  double* Linv;
+  double* logdet;
+  int32_t* info;
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_wave_potrf(PotrfArgs a) {
+  __shared__ __attribute__((aligned(16))) double scr_all[WAVES * DIAG_SCR];
+  __shared__ __attribute__((aligned(16))) double w_all[WAVES * NB * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int m = blockIdx.x * WAVES + wave;
+  if (m >= a.b) return;
+  double* scr = scr_all + wave * DIAG_SCR;
+  double* Wl = w_all + wave * NB * 256;
+  double* A = a.A + (size_t)m * a.T * a.T;
+  const int T = a.T;
+  d4 U[NB * (NB + 1) / 2];
+  d4 R[NB];
+  load_sym_upper<NB>(U, A, T, T, lane);
+  if (a.add != 0.0) add_diag<NB>(U, a.add, T, lane);
+  if (a.jitter_rel != 0.0) {
+    double dm = diag_abs_mean<NB>(U, T, lane);
+    add_diag<NB>(U, a.jitter_rel * fmax(dm, F64_EPS), T, lane);
+  }
+  PivotAcc pa;
+  pa.init();
+  wave_factor<NB, false>(U, R, scr, Wl, lane, pa, A, T, T);
+  // zero the strictly upper blocks of the in-place result (torch.linalg.cholesky returns zeros there)
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int J = I + 1; J < NB; ++J) {
+      const int ln = launder(lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
+        if (i < T && j < T) A[(size_t)i * T + j] = 0.0;
+      }
+    }
+  if (lane == 0) {
+    if (a.info) a.info[m] = pa.info;
+    if (a.logdet) a.logdet[m] = pa.logdet();
+  }
+  if (a.Linv) {
+    double* Z = a.Linv + (size_t)m * T * T;
+    for (int Jc = 0; Jc < NB; ++Jc) {
+#pragma unroll
+      for (int K = 0; K < NB; ++K)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R[K][r] = (K == Jc && g + 4 * r == c) ? 1.0 : 0.0;
+      wave_fwd_solve<NB>(U, Wl, R, lane, Jc);
+#pragma unroll
+      for (int K = 0; K < NB; ++K)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int i = 16 * K + g + 4 * r, j = 16 * Jc + c;
+          if (i < T && j < T) Z[(size_t)i * T + j] = (K >= Jc) ? R[K][r] : 0.0;
+        }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------- a4 + a6
+struct ScoreArgs {
+  const double* Y;
+  int ldy;
+  const double* mean;
+  long mean_stride;
+  const double* Sigma;
+  long sigma_stride;
+  int T;
+  const int32_t* item_mat;
+  const double* item_add;
+  const int32_t* item_off;
+  const int32_t* item_cnt;
+  int n_items;
+  const int32_t* seg_ids;
+  double jitter_rel;
+  double* out_quad;
+  double* out_logdet;
+  int32_t* out_info;
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_wave_score(ScoreArgs a) {
+  __shared__ __attribute__((aligned(16))) double scr_all[WAVES * DIAG_SCR];
+  __shared__ __attribute__((aligned(16))) double w_all[WAVES * NB * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int it = blockIdx.x * WAVES + wave;
+  if (it >= a.n_items) return;
+  double* scr = scr_all + wave * DIAG_SCR;
+  const int T = a.T;
+  const int mat = a.item_mat[it];
+  const double* S = a.Sigma + (size_t)mat * a.sigma_stride;
+  const double* mu = a.mean ? a.mean + (size_t)mat * a.mean_stride : nullptr;
+  d4 U[NB * (NB + 1) / 2];
+  d4 R[NB];
+  double* Wl = w_all + wave * NB * 256;
+  load_sym_upper<NB>(U, S, T, T, lane);
+  const double add = a.item_add ? a.item_add[it] : 0.0;
+  if (add != 0.0) add_diag<NB>(U, add, T, lane);
+  if (a.jitter_rel != 0.0) {
+    double dm = diag_abs_mean<NB>(U, T, lane);
+    add_diag<NB>(U, a.jitter_rel * fmax(dm, F64_EPS), T, lane);
+  }
+  const int off = a.item_off[it], cnt = a.item_cnt[it];
+  PivotAcc pa;
+  pa.init();
+  double ld = 0.0;
+  // the first 16 segments ride along with the factorisation; further chunks reuse the stored factor
+  for (int base = 0; base < cnt; base += 16) {
+    const int j = base + c;
+    const bool live = j < cnt;
+    const int seg = live ? (a.seg_ids ? a.seg_ids[off + j] : off + j) : 0;
+    const double* yr = a.Y + (size_t)seg * a.ldy;
+#pragma unroll
+    for (int K = 0; K < NB; ++K)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = 16 * K + g + 4 * r;
+        double v = 0.0;
+        if (live && i < T) v = yr[i] - (mu ? mu[i] : 0.0);
+        R[K][r] = v;
+      }
+    if (base == 0) {
+      wave_factor<NB, true>(U, R, scr, cnt > 16 ? Wl : nullptr, lane, pa, nullptr, 0, T);
+      ld = pa.logdet();
+    } else {
+      wave_fwd_solve<NB>(U, Wl, R, lane);
+    }
+    double q = wave_colnorm2<NB>(R);
+    if (live && g == 0) {
+      a.out_quad[seg] = q;
+      if (a.out_logdet) a.out_logdet[seg] = ld;
+      if (a.out_info) a.out_info[seg] = pa.info;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------- batched tile GEMM
+// C[b] = op(A[b]) * B[b] on n x n matrices (n a multiple of 16), one wave per 16x16 tile of C.
+// Only used for the per-cluster operators (K matrices per update), never per (segment, cluster).
+template <bool TA>
+__global__ __launch_bounds__(64 * WAVES) void k_gemm16(const double* __restrict__ A, const double* __restrict__ B,
+                                                        double* __restrict__ C, int n) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int nt = n / 16;
+  const int tile = blockIdx.x * WAVES + wave;
+  if (tile >= nt * nt) return;
+  const int ti = tile / nt, tj = tile % nt;
+  const size_t off = (size_t)blockIdx.y * n * n;
+  A += off;
+  B += off;
+  C += off;
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < n / 4; ++kk) {
+    int k = 4 * kk + g;
+    double av = TA ? A[(size_t)k * n + 16 * ti + c] : A[(size_t)(16 * ti + c) * n + k];
+    double bv = B[(size_t)k * n + 16 * tj + c];
+    acc = mfma(av, bv, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) C[(size_t)(16 * ti + g + 4 * r) * n + 16 * tj + c] = acc[r];
+}
+
+// ------------------------------------------------------------------ per-cluster operators (plan)
+// scal[k*8 + ..] : 0 c, 1 ell, 2 noise, 3 iso flag, 4 mean(diag Sigma), 5 jitter of K~
+struct PrepArgs {
+  const double* xb;
+  const double* mean;
+  const double* Sigma;
+  int T, TP, K;
+  const double* theta;  // [K,3] device copy
+  double* scal;         // [K,8]
+  double* A;            // [K,TP,TP] K~ (identity padded)
+  double* S;            // [K,TP,TP] 0.5 (Sigma + Sigma^T) (zero padded)
+  double* xb_copy;      // [TP]
+};
+
+__global__ __launch_bounds__(256) void k_prep_build(PrepArgs a) {
+  __shared__ double red[256];
+  __shared__ int redi[256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int T = a.T, TP = a.TP;
+  const double* Sg = a.Sigma + (size_t)k * T * T;
+  const double c = a.theta[3 * k], ell = a.theta[3 * k + 1], noise = a.theta[3 * k + 2];
+  double s_abs = 0.0, s_sgn = 0.0;
+  for (int i = tid; i < T; i += 256) {
+    double d = Sg[(size_t)i * T + i];
+    s_abs += fabs(d);
+    s_sgn += d;
+  }
+  red[tid] = s_abs;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double mean_abs = red[0] / T;
+  __syncthreads();
+  red[tid] = s_sgn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double mS = red[0] / T;
+  int bad = 0;
+  for (int i = tid; i < T; i += 256) {
+    double d = Sg[(size_t)i * T + i];
+    if (!(fabs(d - mS) <= 1e-8 + 1e-5 * fabs(mS))) bad = 1;   // torch.isclose defaults (GPI.py:497)
+  }
+  redi[tid] = bad;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) redi[tid] |= redi[tid + o];
+    __syncthreads();
+  }
+  const double jit = 1e-4 * fmax(mean_abs, F64_EPS);           // GPI.py:488
+  if (tid == 0) {
+    double* sc = a.scal + 8 * k;
+    sc[0] = c;
+    sc[1] = ell;
+    sc[2] = noise;
+    sc[3] = redi[0] ? 0.0 : 1.0;
+    sc[4] = mS;
+    sc[5] = jit;
+  }
+  if (k == 0)
+    for (int i = tid; i < TP; i += 256) a.xb_copy[i] = (i < T) ? a.xb[i] : 0.0;
+  double* Ak = a.A + (size_t)k * TP * TP;
+  double* Sk = a.S + (size_t)k * TP * TP;
+  for (int idx = tid; idx < TP * TP; idx += 256) {
+    int i = idx / TP, j = idx % TP;
+    double av, sv = 0.0;
+    if (i < T && j < T) {
+      double u = a.xb[i] / ell - a.xb[j] / ell;
+      av = c * exp(-0.5 * (u * u));
+      if (i == j) av += jit;
+      sv = 0.5 * (Sg[(size_t)i * T + j] + Sg[(size_t)j * T + i]);
+    } else {
+      av = (i == j) ? 1.0 : 0.0;
+    }
+    Ak[idx] = av;
+    Sk[idx] = sv;
+  }
+}
+
+struct PrepFinalArgs {
+  const double* Q;      // Kinv * S * Kinv
+  const double* Kinv;
+  const double* mean;   // [K,T]
+  const double* scal;
+  int T, TP;
+  double* Mp;           // [K,TP,TP]
+  double* ap;           // [K,TP]
+};
+
+__global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int T = a.T, TP = a.TP;
+  const double c = a.scal[8 * k];
+  const double* Q = a.Q + (size_t)k * TP * TP;
+  const double* Ki = a.Kinv + (size_t)k * TP * TP;
+  double* Mp = a.Mp + (size_t)k * TP * TP;
+  for (int idx = tid; idx < TP * TP; idx += 256) {
+    int i = idx / TP, j = idx % TP;
+    double v = 0.0;
+    if (i < T && j < T) v = (c * c) * (0.5 * (Q[(size_t)i * TP + j] + Q[(size_t)j * TP + i]) - 0.5 * (Ki[(size_t)i * TP + j] + Ki[(size_t)j * TP + i]));
+    Mp[idx] = v;
+  }
+  const double* mu = a.mean + (size_t)k * T;
+  for (int i = tid; i < TP; i += 256) {
+    double s = 0.0;
+    if (i < T)
+      for (int j = 0; j < T; ++j) s = fma(Ki[(size_t)i * TP + j], mu[j], s);
+    a.ap[(size_t)k * TP + i] = c * s;
+  }
+}
+
+// -------------------------------------------------------------------------------------- a2 + a5
+struct PairsArgs {
+  const double* x;
+  const double* y;
+  int N, Ts;
+  const double* xb;
+  int T;
+  const double* Mp;
+  const double* ap;
+  const double* scal;
+  const int32_t* perm;   // sorted position -> original cluster id
+  int kbeg, kend;        // range of sorted positions sharing one length-scale
+  double ell;
+  const double* first_noise;
+  int K;
+  double* out_quad;
+  double* out_logdet;
+  int32_t* out_info;
+};
+
+template <int NB>
+constexpr size_t pairs_lds_bytes() {
+  return sizeof(double) * ((size_t)(16 * NB) * (16 * NB) + 3 * 16 * NB + WAVES * DIAG_SCR + WAVES * 16 * NB);
+}
+
+// One workgroup per segment n; its 4 waves take the clusters of the length-scale group round-robin.
+// E_n = exp(-0.5 ((xb_k - x_j)/ell)^2) is built once per workgroup in LDS and shared by the waves; each
+// wave then evaluates one (segment, cluster) pair entirely in its own registers:
+//   cov = c R_n + noise I + E^T M'_k E   (two MFMA GEMM sweeps, the first result feeding the second
+//   straight from the accumulators), regularise, factor, forward-solve, reduce.
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
+  constexpr int TP = 16 * NB;
+  constexpr int NS = TP / 4;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* E = smem;               // [TP][TP]: row k = basis point, column j = segment point
+  double* xs = E + TP * TP;       // segment grid / ell
+  double* ys = xs + TP;
+  double* xbs = ys + TP;          // basis grid / ell
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  double* scr = xbs + TP + wave * DIAG_SCR;
+  double* dv = xbs + TP + WAVES * DIAG_SCR + wave * TP;
+  const int n = blockIdx.x;
+  const int T = a.T, Ts = a.Ts;
+
+  for (int i = tid; i < TP; i += 64 * WAVES) {
+    xs[i] = (i < Ts) ? a.x[(size_t)n * Ts + i] / a.ell : 0.0;
+    ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
+    xbs[i] = (i < T) ? a.xb[i] / a.ell : 0.0;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < TP * TP; idx += 64 * WAVES) {
+    int k = idx / TP, j = idx % TP;
+    double v = 0.0;
+    if (k < T && j < Ts) {
+      double u = xbs[k] - xs[j];
+      v = exp(-0.5 * (u * u));
+    }
+    E[idx] = v;
+  }
+  __syncthreads();
+
+  for (int kk = a.kbeg + wave; kk < a.kend; kk += WAVES) {
+    const int lane = launder(tid) & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const int kc = a.perm[kk];
+    const double* sc = a.scal + 8 * kc;
+    const double cc = sc[0], noise = sc[2];
+    const bool iso = sc[3] != 0.0;
+    const double fn = a.first_noise ? a.first_noise[(size_t)n * a.K + kc] : 0.0;
+    const size_t oidx = (size_t)n * a.K + kc;
+
+    // d = y - E^T a'   (a' = c K~^{-1} mean)
+    const double* apk = a.ap + (size_t)kc * TP;
+    double dsq = 0.0;
+    for (int j = lane; j < TP; j += 64) {
+      double f = 0.0;
+      for (int k = 0; k < T; ++k) f = fma(E[k * TP + j], apk[k], f);
+      double d = (j < Ts) ? ys[j] - f : 0.0;
+      dv[j] = d;
+      dsq = fma(d, d, dsq);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    if (iso) {   // GPI.py:497-498: cov_f = mean(diag Sigma) I
+      double v = sc[4] + fn;
+      double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
+      double q = wave_sum(dsq) / v2;
+      if (lane == 0) {
+        a.out_quad[oidx] = q;
+        if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
+        if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
+      }
+      continue;
+    }
+
+    // cov tiles (upper): K** = c exp(-0.5 (x_i - x_j)^2 / ell^2) + noise I   (one-argument kernel call, GPI.py:476)
+    d4 cov[NB * (NB + 1) / 2];
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ln = launder(lane);
+          int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
+          double v = 0.0;
+          if (i < Ts && j < Ts) {
+            double u = xs[i] - xs[j];
+            v = (i == j) ? cc + noise : cc * exp(-0.5 * (u * u));
+          } else if (i == j) {
+            v = 1.0;
+          }
+          cov[tix(I, J, NB)][r] = v;
+          __builtin_amdgcn_sched_barrier(0);   // one exp at a time: interleaving 144 of them explodes the live set
+        }
+
+    // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
+    // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
+    constexpr int NH = NB / 2;
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      const double* Ej = E + g * TP + 16 * J + c;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // sweep 1: BJ = M'[16 NH h .. , :] E[:, J]; M' is symmetric, so row-tile I of the A operand is read as
+        // M'[k][16 I + c]: 128 contiguous bytes per 16 lanes.  4-deep register ring over the k-steps.
+        const double* Mk = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP + 16 * NH * h + c;
+        d4 BJ[NH];
+#pragma unroll
+        for (int I = 0; I < NH; ++I) BJ[I] = (d4){0.0, 0.0, 0.0, 0.0};
+        double ar0[NH], ar1[NH], ar2[NH], ar3[NH];
+#pragma unroll
+        for (int I = 0; I < NH; ++I) {
+          ar0[I] = Mk[16 * I];
+          ar1[I] = Mk[(size_t)4 * TP + 16 * I];
+          ar2[I] = Mk[(size_t)8 * TP + 16 * I];
+        }
+#pragma nounroll
+        for (int s = 0; s < NS; s += 4) {
+          const double* Ms = Mk + (size_t)4 * s * TP;
+          const double* Es = Ej + (size_t)4 * s * TP;
+          {
+#pragma unroll
+            for (int I = 0; I < NH; ++I) ar3[I] = Ms[(size_t)12 * TP + 16 * I];
+            double b = Es[0];
+#pragma unroll
+            for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar0[I], b, BJ[I]);
+          }
+          const bool more = s + 4 < NS;
+          {
+            if (more) {
+#pragma unroll
+              for (int I = 0; I < NH; ++I) ar0[I] = Ms[(size_t)16 * TP + 16 * I];
+            }
+            double b = Es[4 * TP];
+#pragma unroll
+            for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar1[I], b, BJ[I]);
+          }
+          {
+            if (more) {
+#pragma unroll
+              for (int I = 0; I < NH; ++I) ar1[I] = Ms[(size_t)20 * TP + 16 * I];
+            }
+            double b = Es[8 * TP];
+#pragma unroll
+            for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar2[I], b, BJ[I]);
+          }
+          {
+            if (more) {
+#pragma unroll
+              for (int I = 0; I < NH; ++I) ar2[I] = Ms[(size_t)24 * TP + 16 * I];
+            }
+            double b = Es[12 * TP];
+#pragma unroll
+            for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar3[I], b, BJ[I]);
+          }
+        }
+        // sweep 2: cov[I][J] += E[rows h, I]^T BJ   (B operand = the accumulators of sweep 1, untouched)
+#pragma unroll
+        for (int Kt = 0; Kt < NH; ++Kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double* Er = E + (16 * (NH * h + Kt) + 4 * r + g) * TP + c;
+#pragma unroll
+            for (int I = 0; I <= J; ++I) cov[tix(I, J, NB)] = mfma(Er[16 * I], BJ[Kt][r], cov[tix(I, J, NB)]);
+          }
+      }
+    }
+
+    // regularisation of the reference: +1e-6 I (GPI.py:501), + first, + 1e-8 mean|diag| I (GPI_model.py:83-87)
+    add_diag<NB>(cov, 1e-6, Ts, lane);
+    if (fn != 0.0) add_diag<NB>(cov, fn, Ts, lane);
+    {
+      double dm = diag_abs_mean<NB>(cov, Ts, lane);
+      add_diag<NB>(cov, 1e-8 * fmax(dm, F64_EPS), Ts, lane);
+    }
+    PivotAcc pa;
+    pa.init();
+    d4 R[NB];
+#pragma unroll
+    for (int K = 0; K < NB; ++K)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R[K][r] = (c == 0) ? dv[16 * K + g + 4 * r] : 0.0;
+    wave_factor<NB, true>(cov, R, scr, nullptr, lane, pa, nullptr, 0, Ts);
+    double q = wave_colnorm2<NB>(R);
+    if (lane == 0) {
+      a.out_quad[oidx] = q;
+      if (a.out_logdet) a.out_logdet[oidx] = pa.logdet();
+      if (a.out_info) a.out_info[oidx] = pa.info;
+    }
+  }
+}
+
+template <int NB>
+int launch_pairs(const PairsArgs& a, hipStream_t st) {
+  size_t lds = pairs_lds_bytes<NB>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_pairs<NB>, dim3(a.N), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+struct hgp_pairs_plan {
+  int T, K, TP, NB;
+  std::vector<double> theta;           // host copy [K,3]
+  std::vector<int32_t> perm;           // clusters sorted by length-scale
+  std::vector<int> grp_beg, grp_end;   // ranges of `perm` sharing one length-scale
+  std::vector<double> grp_ell;
+  // device carve-up
+  double *d_theta, *d_scal, *d_A, *d_S, *d_Z, *d_Kinv, *d_P, *d_Q, *d_Mp, *d_ap, *d_xb;
+  int32_t* d_perm;
+};
+
+static size_t plan_bytes(int T, int Ts_max, int K, size_t* offs /*[12]*/) {
+  const size_t TP = 16 * (size_t)nb_for(std::max(T, Ts_max));
+  const size_t mat = (size_t)K * TP * TP * sizeof(double);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o += (bytes + 255) & ~(size_t)255;
+    return at;
+  };
+  size_t tmp[12];
+  tmp[0] = take((size_t)K * 3 * sizeof(double));   // theta
+  tmp[1] = take((size_t)K * 8 * sizeof(double));   // scal
+  tmp[2] = take(mat);                              // A  (K~ then L)
+  tmp[3] = take(mat);                              // S
+  tmp[4] = take(mat);                              // Z
+  tmp[5] = take(mat);                              // Kinv
+  tmp[6] = take(mat);                              // P
+  tmp[7] = take(mat);                              // Q
+  tmp[8] = take(mat);                              // Mp
+  tmp[9] = take((size_t)K * TP * sizeof(double));  // ap
+  tmp[10] = take((size_t)K * sizeof(int32_t));     // perm
+  tmp[11] = take(TP * sizeof(double));             // x_basis copy
+  if (offs) memcpy(offs, tmp, sizeof(tmp));
+  return o;
+}
+
+extern "C" {
+
+int hgp_abi_version(void) { return HGP_ABI_VERSION; }
+
+int hgp_debug_mfma_f64(const double* A, const double* B, double* C, void* stream) {
+  if (!A || !B || !C) return -1;
+  hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, C);
+  return launch_status();
+}
+
+int hgp_gram_rbf_f64(const double* x, int nx, const double* y, int ny, double c, double ell, double noise,
+                     double* K_out, void* stream) {
+  if (!x || !K_out || nx <= 0 || ell <= 0.0) return -1;
+  const int one = (y == nullptr);
+  if (one) ny = nx;
+  if (ny <= 0) return -1;
+  size_t tot = (size_t)nx * ny;
+  hipLaunchKernelGGL(k_gram_rbf, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, nx, y, ny, c,
+                     ell, noise, one, K_out);
+  return launch_status();
+}
+
+int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add_diag, double* Linv, double* logdet,
+                          int32_t* info, void* stream) {
+  if (!A || T <= 0 || b < 0) return -1;
+  if (b == 0) return 0;
+  if (T > HGP_MAX_T_WAVE) return -2;
+  PotrfArgs a{A, T, b, jitter_rel, add_diag, Linv, logdet, info};
+  dim3 grid((b + WAVES - 1) / WAVES), blk(64 * WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nb_for(T)) {
+    case 2: hipLaunchKernelGGL(k_wave_potrf<2>, grid, blk, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_wave_potrf<4>, grid, blk, 0, st, a); break;
+    case 6: hipLaunchKernelGGL(k_wave_potrf<6>, grid, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL(k_wave_potrf<8>, grid, blk, 0, st, a); break;
+  }
+  return launch_status();
+}
+
+int hgp_score_groups_f64(const double* Y, int ldy, const double* mean, long mean_stride, const double* Sigma,
+                         long sigma_stride, int T, const int32_t* item_mat, const double* item_add,
+                         const int32_t* item_off, const int32_t* item_cnt, int n_items, const int32_t* seg_ids,
+                         double jitter_rel, double* out_quad, double* out_logdet, int32_t* out_info, void* stream) {
+  if (!Y || !Sigma || !item_mat || !item_off || !item_cnt || !out_quad || T <= 0 || ldy < T || n_items < 0) return -1;
+  if (n_items == 0) return 0;
+  if (T > HGP_MAX_T_WAVE) return -2;
+  ScoreArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, item_mat, item_add, item_off, item_cnt, n_items,
+              seg_ids, jitter_rel, out_quad, out_logdet, out_info};
+  dim3 grid((n_items + WAVES - 1) / WAVES), blk(64 * WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nb_for(T)) {
+    case 2: hipLaunchKernelGGL(k_wave_score<2>, grid, blk, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_wave_score<4>, grid, blk, 0, st, a); break;
+    case 6: hipLaunchKernelGGL(k_wave_score<6>, grid, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL(k_wave_score<8>, grid, blk, 0, st, a); break;
+  }
+  return launch_status();
+}
+
+size_t hgp_pairs_plan_device_bytes(int T, int Ts_max, int K) {
+  if (T <= 0 || Ts_max <= 0 || K <= 0) return 0;
+  return plan_bytes(T, Ts_max, K, nullptr);
+}
+
+int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const double* theta_host, void* dev_buf,
+                          size_t dev_bytes) {
+  if (!plan || !theta_host || !dev_buf || T <= 0 || Ts_max <= 0 || K <= 0) return -1;
+  if (T > HGP_MAX_T_WAVE || Ts_max > HGP_MAX_T_WAVE) return -2;
+  size_t offs[12];
+  if (dev_bytes < plan_bytes(T, Ts_max, K, offs)) return -1;
+  for (int k = 0; k < K; ++k)
+    if (!(theta_host[3 * k] > 0.0) || !(theta_host[3 * k + 1] > 0.0)) return -1;
+  hgp_pairs_plan* p = new (std::nothrow) hgp_pairs_plan();
+  if (!p) return -1;
+  p->T = T;
+  p->K = K;
+  p->NB = nb_for(std::max(T, Ts_max));
+  p->TP = 16 * p->NB;
+  p->theta.assign(theta_host, theta_host + 3 * (size_t)K);
+  p->perm.resize(K);
+  for (int k = 0; k < K; ++k) p->perm[k] = k;
+  std::stable_sort(p->perm.begin(), p->perm.end(),
+                   [&](int a, int b) { return p->theta[3 * a + 1] < p->theta[3 * b + 1]; });
+  for (int i = 0; i < K;) {
+    int j = i;
+    double ell = p->theta[3 * p->perm[i] + 1];
+    while (j < K && p->theta[3 * p->perm[j] + 1] == ell) ++j;
+    p->grp_beg.push_back(i);
+    p->grp_end.push_back(j);
+    p->grp_ell.push_back(ell);
+    i = j;
+  }
+  char* base = (char*)dev_buf;
+  p->d_theta = (double*)(base + offs[0]);
+  p->d_scal = (double*)(base + offs[1]);
+  p->d_A = (double*)(base + offs[2]);
+  p->d_S = (double*)(base + offs[3]);
+  p->d_Z = (double*)(base + offs[4]);
+  p->d_Kinv = (double*)(base + offs[5]);
+  p->d_P = (double*)(base + offs[6]);
+  p->d_Q = (double*)(base + offs[7]);
+  p->d_Mp = (double*)(base + offs[8]);
+  p->d_ap = (double*)(base + offs[9]);
+  p->d_perm = (int32_t*)(base + offs[10]);
+  p->d_xb = (double*)(base + offs[11]);
+  if (hipMemcpy(p->d_theta, p->theta.data(), sizeof(double) * 3 * K, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->d_perm, p->perm.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice) != hipSuccess) {
+    delete p;
+    return 1000 + (int)hipGetLastError();
+  }
+  *plan = p;
+  return 0;
+}
+
+void hgp_pairs_plan_destroy(hgp_pairs_plan* plan) { delete plan; }
+
+int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double* mean, const double* Sigma,
+                          int32_t* info, void* stream) {
+  if (!p || !x_basis || !mean || !Sigma) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int K = p->K, T = p->T, TP = p->TP;
+  PrepArgs pa{x_basis, mean, Sigma, T, TP, K, p->d_theta, p->d_scal, p->d_A, p->d_S, p->d_xb};
+  hipLaunchKernelGGL(k_prep_build, dim3(K), dim3(256), 0, st, pa);
+  // L = chol(K~) in place, Z = L^{-1}
+  PotrfArgs fa{p->d_A, TP, K, 0.0, 0.0, p->d_Z, nullptr, info};
+  dim3 fgrid((K + WAVES - 1) / WAVES), blk(64 * WAVES);
+  switch (p->NB) {
+    case 2: hipLaunchKernelGGL(k_wave_potrf<2>, fgrid, blk, 0, st, fa); break;
+    case 4: hipLaunchKernelGGL(k_wave_potrf<4>, fgrid, blk, 0, st, fa); break;
+    case 6: hipLaunchKernelGGL(k_wave_potrf<6>, fgrid, blk, 0, st, fa); break;
+    default: hipLaunchKernelGGL(k_wave_potrf<8>, fgrid, blk, 0, st, fa); break;
+  }
+  const int nt = TP / 16;
+  dim3 ggrid((nt * nt + WAVES - 1) / WAVES, K);
+  hipLaunchKernelGGL(k_gemm16<true>, ggrid, blk, 0, st, p->d_Z, p->d_Z, p->d_Kinv, TP);      // Kinv = Z^T Z
+  hipLaunchKernelGGL(k_gemm16<false>, ggrid, blk, 0, st, p->d_S, p->d_Kinv, p->d_P, TP);     // P = S Kinv
+  hipLaunchKernelGGL(k_gemm16<false>, ggrid, blk, 0, st, p->d_Kinv, p->d_P, p->d_Q, TP);     // Q = Kinv S Kinv
+  PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap};
+  hipLaunchKernelGGL(k_prep_final, dim3(K), dim3(256), 0, st, fin);
+  return launch_status();
+}
+
+int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double* y, int N, int Ts,
+                         const double* first_noise, double* out_quad, double* out_logdet, int32_t* out_info,
+                         void* stream) {
+  if (!p || !x || !y || !out_quad || N < 0 || Ts <= 0) return -1;
+  if (N == 0) return 0;
+  if (Ts > HGP_MAX_T_WAVE) return -2;
+  if (nb_for(Ts) > p->NB) return -2;   // plan was created with a smaller Ts_max
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 0;
+  for (size_t gi = 0; gi < p->grp_beg.size() && rc == 0; ++gi) {
+    PairsArgs a{x, y, N, Ts, p->d_xb, p->T, p->d_Mp, p->d_ap, p->d_scal, p->d_perm, p->grp_beg[gi], p->grp_end[gi],
+                p->grp_ell[gi], first_noise, p->K, out_quad, out_logdet, out_info};
+    switch (p->NB) {
+      case 2: rc = launch_pairs<2>(a, st); break;
+      case 4: rc = launch_pairs<4>(a, st); break;
+      case 6: rc = launch_pairs<6>(a, st); break;
+      default: rc = launch_pairs<8>(a, st); break;
+    }
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// Wave-level fp64 tile algebra for gfx950 (MI355X): one 64-lane wavefront owns a whole symmetric
+// matrix of up to 128x128 as 16x16 tiles held in the MFMA accumulator layout, factors it with
+// v_mfma_f64_16x16x4_f64 and solves against right-hand sides without leaving registers.
+//
+// Tile layout ("acc layout", the C/D map of v_mfma_f64_16x16x4_f64): lane l = 16*g + c holds
+//   v[r] = X[g + 4r][c],  r = 0..3.
+// MFMA operand maps (one double per lane per k-step of 4):  A-op  a = A[c][g],  B-op  b = B[g][c].
+// Two identities make the whole factorisation register-resident:
+//   (1) an acc tile X is directly the B operand of k-step s:  b_s = X[4s+g][c] = v[s];
+//   (2) the same register is the A operand of X^T:            a_s = X^T[c][4s+g] = v[s].
+// Hence  mfma(X.v[s], Y.v[s]) summed over s = X^T Y, which is exactly the trailing update of an
+// UPPER-form Cholesky  A = U^T U  (U_KJ tiles, K <= J):   A_IJ -= U_KI^T U_KJ.
+//
+// Only the 16x16 diagonal blocks need cross-lane work (diag16 below); every other flop is MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hgp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int DIAG_LD = 18;              // row stride (doubles) of the per-wave 16x16 LDS staging tile
+constexpr int DIAG_SCR = 16 * DIAG_LD;   // doubles of LDS scratch each wave needs
+constexpr double F64_EPS = 2.220446049250313e-16;
+
+__host__ __device__ constexpr int tix(int I, int J, int NB) { return I * NB - (I * (I - 1)) / 2 + (J - I); }
+__host__ __device__ constexpr int ntiles(int NB) { return NB * (NB + 1) / 2; }
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// value of lane `src` (compile-time constant after unrolling) broadcast to the whole wave through SGPRs
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Opaque copy of a per-lane value.  Everything below is fully unrolled over tiles; without this the
+// compiler hoists hundreds of loop-invariant lane predicates and LDS addresses to the kernel entry and
+// spills them.  Recomputing them next to their use costs a few VALU ops per tile.
+__device__ __forceinline__ int launder(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// log-determinant accumulator (product of pivots kept as mantissa * 2^ex) + LAPACK-style info
+struct PivotAcc {
+  double mant;
+  int ex;
+  int info;  // 0 = ok, j > 0 = pivot j (1-based) was not positive
+  __device__ __forceinline__ void init() { mant = 1.0; ex = 0; info = 0; }
+  __device__ __forceinline__ void renorm() {
+    ex += __builtin_amdgcn_frexp_exp(mant);
+    mant = __builtin_amdgcn_frexp_mant(mant);
+  }
+  // log of the product of the squared pivots u_kk^2 = log det(A)
+  __device__ __forceinline__ double logdet() const { return log(mant) + (double)ex * 0.6931471805599453; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// diag16: Cholesky of one 16x16 diagonal block AND the inverse of its factor, by one wave.
+//   in : X  (acc layout; only the upper triangle i <= j is read)
+//   out: returns W = L^{-1} (L = U^T lower) in A-operand layout, w[s] = W[c][4s+g];
+//        if Lout != nullptr lane j < 16 writes row j of L (zeros above the diagonal).
+// Lanes 0..15 hold column j of U (Crout, row by row); lanes 16..31 run the forward substitution
+// L Z = I on column j of Z with the SAME instruction stream: both need the scalars U[m][k]
+// (= L[k][m]), which are broadcast from lane k with v_readlane.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
+                                     double* Lout, int ldl, int nvalid) {
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) scr[(g + 4 * r) * DIAG_LD + c] = X[r];
+  __builtin_amdgcn_wave_barrier();
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double x = scr[i * DIAG_LD + c];                       // X[i][c]: column c (upper part is what matters)
+    double e = (c == i && lane < 32) ? 1.0 : 0.0;          // identity column for the Z lanes
+    v[i] = (lane < 16) ? x : e;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    double acc = v[k];
+#pragma unroll
+    for (int m = 0; m < k; ++m) {
+      double s = lane_bcast(v[m], k);                      // U[m][k]
+      acc = fma(-s, v[m], acc);
+    }
+    double piv = lane_bcast(acc, k);                       // u_kk^2
+    bool okp = piv > 0.0;                                  // NaN compares false
+    if (!okp && pa.info == 0) pa.info = col0 + k + 1;
+    piv = okp ? piv : 1.0;
+    pa.mant *= __builtin_amdgcn_frexp_mant(piv);
+    pa.ex += __builtin_amdgcn_frexp_exp(piv);
+    double rinv = 1.0 / sqrt(piv);
+    v[k] = acc * rinv;
+    __builtin_amdgcn_sched_barrier(0);   // keep step k's broadcasts next to their FMAs
+  }
+  pa.renorm();
+  if (Lout != nullptr && lane < 16 && lane < nvalid) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < nvalid) Lout[(size_t)lane * ldl + i] = (i <= lane) ? v[i] : 0.0;   // L[j][i] = U[i][j]
+  }
+  if (lane >= 16 && lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) scr[i * DIAG_LD + c] = v[i];                     // Z[i][j], j = c
+  }
+  __builtin_amdgcn_wave_barrier();
+  d4 w;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) w[s] = scr[c * DIAG_LD + 4 * s + g];                // W[c][4s+g]
+  __builtin_amdgcn_wave_barrier();
+  return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Upper-form blocked Cholesky of an NB x NB tile matrix held in registers (upper tiles only),
+// right-looking, with ONE block column of 16 right-hand sides eliminated in the same sweep:
+//   on exit R[K] = Z_K with L Z = R_in (L = U^T), so  rhs^T A^{-1} rhs = column sums of Z.^2 .
+// The inverses of the diagonal factors, W_K = U_KK^{-T} (A-operand layout), are transient unless
+// Wlds != nullptr, in which case they are kept in LDS ([K][s][lane]) for later wave_fwd_solve calls.
+// If Lout != nullptr the lower factor L = U^T is written row-major (ld = ldl) for rows/cols < n.
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool RHS>
+__device__ __forceinline__ void wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[NB], double* scr, double* Wlds,
+                                            int lane_in, PivotAcc& pa, double* Lout, int ldl, int n) {
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+    double* Ld = (Lout != nullptr) ? Lout + (size_t)(16 * K) * ldl + 16 * K : nullptr;
+    const d4 W = diag16(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
+    if (Wlds != nullptr) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Wlds[(K * 4 + s) * 64 + lane] = W[s];
+    }
+    // panel: U_KJ = U_KK^{-T} A_KJ = W * A_KJ  for J > K, and the rhs tile (J == NB); two tiles in flight
+#pragma unroll
+    for (int J0 = K + 1; J0 <= NB; J0 += 2) {
+      d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+      const int J1 = J0 + 1;
+      const bool has0 = (J0 < NB) || RHS, has1 = (J1 < NB) || (RHS && J1 == NB);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (has0) acc0 = mfma(W[s], (J0 < NB) ? U[tix(K, J0 < NB ? J0 : K, NB)][s] : R[K][s], acc0);
+        if (has1) acc1 = mfma(W[s], (J1 < NB) ? U[tix(K, J1 < NB ? J1 : K, NB)][s] : R[K][s], acc1);
+      }
+      if (J0 < NB) U[tix(K, J0 < NB ? J0 : K, NB)] = acc0;
+      else if (RHS) R[K] = acc0;
+      if (J1 < NB) U[tix(K, J1 < NB ? J1 : K, NB)] = acc1;
+      else if (RHS && J1 == NB) R[K] = acc1;
+    }
+    if (Lout != nullptr) {
+#pragma unroll
+      for (int J = K + 1; J < NB; ++J) {
+        // L[16J + c][16K + g + 4r] = U_KJ[g + 4r][c]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = 16 * J + c, col = 16 * K + g + 4 * r;
+          if (row < n && col < n) Lout[(size_t)row * ldl + col] = U[tix(K, J, NB)][r];
+        }
+      }
+    }
+    // trailing update: A_IJ -= U_KI^T U_KJ  for K < I <= J  (and the rhs tiles I > K)
+#pragma unroll
+    for (int I = K + 1; I < NB; ++I) {
+      const d4 nu = -U[tix(K, I, NB)];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int J = I; J < NB; ++J) U[tix(I, J, NB)] = mfma(nu[s], U[tix(K, J, NB)][s], U[tix(I, J, NB)]);
+        if (RHS) R[I] = mfma(nu[s], R[K][s], R[I]);
+      }
+    }
+  }
+}
+
+// Forward substitution  L Z = R  (L = U^T) on one more block column of 16 right-hand sides, with the
+// stored factor: U tiles in registers, W_K in LDS (written by wave_factor).  Tiles K < K0 of the
+// right-hand side are taken as zero (used for the columns of L^{-1}).
+template <int NB>
+__device__ __forceinline__ void wave_fwd_solve(const d4 (&U)[NB * (NB + 1) / 2], const double* Wlds, d4 (&R)[NB],
+                                               int lane, int K0 = 0) {
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+    if (K < K0) continue;
+    d4 t = R[K];
+#pragma unroll
+    for (int I = 0; I < K; ++I) {
+      if (I < K0) continue;
+      const d4 nu = -U[tix(I, K, NB)];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t = mfma(nu[s], R[I][s], t);     // t -= U_IK^T Z_I
+    }
+    d4 z = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) z = mfma(Wlds[(K * 4 + s) * 64 + lane], t[s], z);   // Z_K = W_K t
+    R[K] = z;
+  }
+}
+
+// sum of squares of every rhs column: returns in each lane the value for ITS column c (all g agree)
+template <int NB>
+__device__ __forceinline__ double wave_colnorm2(const d4 (&Z)[NB]) {
+  double s = 0.0;
+#pragma unroll
+  for (int K = 0; K < NB; ++K)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s = fma(Z[K][r], Z[K][r], s);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loaders.  A is row-major with leading dimension ld, logical size n x n (n <= 16 NB); rows/cols
+// >= n are padded with the identity so the padded factorisation leaves quad/logdet unchanged.
+// ---------------------------------------------------------------------------------------------
+// symmetrised upper tiles:  0.5 (A + A^T)
+template <int NB>
+__device__ __forceinline__ void load_sym_upper(d4 (&U)[NB * (NB + 1) / 2], const double* __restrict__ A, int ld, int n,
+                                               int lane_in) {
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+#pragma unroll
+    for (int J = I; J < NB; ++J) {
+      const int lane = launder(lane_in);
+      const int g = lane >> 4, c = lane & 15;
+      d4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = 16 * I + g + 4 * r, j = 16 * J + c;
+        double x = 0.0;
+        if (i < n && j < n) x = 0.5 * (A[(size_t)i * ld + j] + A[(size_t)j * ld + i]);
+        else if (i == j) x = 1.0;
+        v[r] = x;
+      }
+      U[tix(I, J, NB)] = v;
+    }
+  }
+}
+
+// add `shift` to the diagonal entries i < n (padded rows keep their 1)
+template <int NB>
+__device__ __forceinline__ void add_diag(d4 (&U)[NB * (NB + 1) / 2], double shift, int n, int lane_in) {
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int i = 16 * I + g + 4 * r;
+      if (g + 4 * r == c && i < n) U[tix(I, I, NB)][r] += shift;
+    }
+  }
+}
+
+// mean over i < n of |A_ii| taken from the diagonal tiles
+template <int NB>
+__device__ __forceinline__ double diag_abs_mean(const d4 (&U)[NB * (NB + 1) / 2], int n, int lane_in) {
+  double s = 0.0;
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int i = 16 * I + g + 4 * r;
+      if (g + 4 * r == c && i < n) s += fabs(U[tix(I, I, NB)][r]);
+    }
+  }
+  return wave_sum(s) / (double)n;
+}
+
+}  // namespace hgp

@@ -1,0 +1,175 @@
+"""Tensor-level wrappers over the C-ABI.  torch tensors are device containers only: every function
+takes fp64 CUDA (ROCm) tensors, enqueues HIP kernels on the current stream and returns tensors."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+LOG2PI = math.log(2.0 * math.pi)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev64(t, name):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous fp64 tensor on the GPU")
+    return t
+
+
+def raise_on_info(info, what):
+    """Mirror torch.linalg.cholesky's error behaviour from a per-item LAPACK info tensor (host sync)."""
+    bad = torch.nonzero(info)
+    if bad.numel():
+        i = int(bad[0, 0])
+        raise torch.linalg.LinAlgError(
+            f"{what}: (Batch element {i}): The factorization could not be completed because the input is not "
+            f"positive-definite (the leading minor of order {int(info.flatten()[i])} is not positive-definite).")
+
+
+def gram_rbf(x, y, c, ell, noise=0.0):
+    """a1: (ConstantKernel(c)*RBF(ell)+WhiteKernel(noise))(x, y); y=None is the one-argument call."""
+    x = _dev64(x.reshape(-1), "x")
+    yv = None if y is None else _dev64(y.reshape(-1), "y")
+    ny = x.numel() if yv is None else yv.numel()
+    K = torch.empty((x.numel(), ny), dtype=torch.float64, device=x.device)
+    _ffi.check(_ffi.lib.hgp_gram_rbf_f64(_ptr(x), x.numel(), _ptr(yv), ny, c, ell, noise, _ptr(K), _stream()), "gram_rbf")
+    return K
+
+
+def potrf_batched(A, jitter_rel=1e-8, add_diag=0.0, want_inv=False, want_logdet=False):
+    """a3: batched GPI_model._chol_spd.  A [b,T,T] (not modified).  Returns (L, info[, Linv][, logdet])."""
+    A = _dev64(A, "A")
+    if A.dim() == 2:
+        A = A.unsqueeze(0)
+    b, T, _ = A.shape
+    L = A.clone()
+    info = torch.zeros(b, dtype=torch.int32, device=A.device)
+    Linv = torch.empty_like(L) if want_inv else None
+    logdet = torch.empty(b, dtype=torch.float64, device=A.device) if want_logdet else None
+    _ffi.check(_ffi.lib.hgp_potrf_batched_f64(_ptr(L), T, b, jitter_rel, add_diag, _ptr(Linv), _ptr(logdet), _ptr(info),
+                                              _stream()), "potrf_batched")
+    out = [L, info]
+    if want_inv:
+        out.append(Linv)
+    if want_logdet:
+        out.append(logdet)
+    return tuple(out)
+
+
+MAX_CHUNK = 64  # segments per work item: one factorisation is reused for up to this many right-hand sides
+
+
+def build_items(mat_of_group, add_of_group, group_sizes):
+    """Split groups (segments sorted by group) into work items of at most MAX_CHUNK segments."""
+    item_mat, item_add, item_off, item_cnt = [], [], [], []
+    off = 0
+    for m, a, n in zip(mat_of_group, add_of_group, group_sizes):
+        done = 0
+        while done < n:
+            c = min(MAX_CHUNK, n - done)
+            item_mat.append(m)
+            item_add.append(a)
+            item_off.append(off + done)
+            item_cnt.append(c)
+            done += c
+        off += n
+    return (np.asarray(item_mat, np.int32), np.asarray(item_add, np.float64), np.asarray(item_off, np.int32),
+            np.asarray(item_cnt, np.int32))
+
+
+def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids=None, jitter_rel=1e-8,
+                 want_logdet=False, want_info=True):
+    """a4+a6: quad[n] = (Y[n]-mean[s])^T cov_s^{-1} (Y[n]-mean[s]) for the segments of each work item.
+
+    Y [N,T]; mean [S,T] or None; Sigma [S,T,T]; item_* host or device int/float arrays; seg_ids [sum cnt] or None.
+    """
+    Y = _dev64(Y, "Y")
+    Sigma = _dev64(Sigma, "Sigma")
+    dev = Y.device
+    N, T = Y.shape
+    if Sigma.dim() == 2:
+        Sigma = Sigma.unsqueeze(0)
+    if mean is not None:
+        mean = _dev64(mean.reshape(-1, T), "mean")
+
+    def up(a, dt):
+        return a.to(device=dev, dtype=dt).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+
+    im, ia = up(item_mat, torch.int32), (None if item_add is None else up(item_add, torch.float64))
+    io, ic = up(item_off, torch.int32), up(item_cnt, torch.int32)
+    sid = None if seg_ids is None else up(seg_ids, torch.int32)
+    quad = torch.zeros(N, dtype=torch.float64, device=dev)
+    logdet = torch.zeros(N, dtype=torch.float64, device=dev) if want_logdet else None
+    info = torch.zeros(N, dtype=torch.int32, device=dev) if want_info else None
+    _ffi.check(_ffi.lib.hgp_score_groups_f64(_ptr(Y), T, _ptr(mean), T, _ptr(Sigma), T * T, T, _ptr(im), _ptr(ia), _ptr(io),
+                                             _ptr(ic), im.numel(), _ptr(sid), jitter_rel, _ptr(quad), _ptr(logdet),
+                                             _ptr(info), _stream()), "score_groups")
+    return quad, logdet, info
+
+
+class PairsPlan:
+    """a2+a5 for an N x K batch: per-cluster operators (plan) + the per-pair kernel."""
+
+    def __init__(self, T, Ts_max, theta, device="cuda"):
+        theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(-1, 3))
+        self.T, self.Ts_max, self.K = int(T), int(Ts_max), theta.shape[0]
+        self.theta = theta
+        nbytes = _ffi.lib.hgp_pairs_plan_device_bytes(self.T, self.Ts_max, self.K)
+        if nbytes == 0:
+            raise ValueError("bad plan shape")
+        self._buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._h = ctypes.c_void_p()
+        _ffi.check(_ffi.lib.hgp_pairs_plan_create(ctypes.byref(self._h), self.T, self.Ts_max, self.K,
+                                                  theta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                  _ptr(self._buf), nbytes), "pairs_plan_create")
+        self.info = torch.zeros(self.K, dtype=torch.int32, device=device)
+
+    def update(self, x_basis, mean, Sigma):
+        """x_basis [T]; mean [K,T] (= C f on the basis grid); Sigma [K,T,T]."""
+        x_basis = _dev64(x_basis.reshape(-1), "x_basis")
+        mean = _dev64(mean.reshape(self.K, self.T), "mean")
+        Sigma = _dev64(Sigma.reshape(self.K, self.T, self.T), "Sigma")
+        self._keep = (x_basis, mean, Sigma)
+        _ffi.check(_ffi.lib.hgp_pairs_plan_update(self._h, _ptr(x_basis), _ptr(mean), _ptr(Sigma), _ptr(self.info),
+                                                  _stream()), "pairs_plan_update")
+        return self
+
+    def loglik(self, x, y, first_noise=None, want_logdet=True, want_info=True):
+        """x, y [N,Ts] -> (quad [N,K], logdet [N,K] or None, info [N,K] or None)."""
+        x = _dev64(x, "x")
+        y = _dev64(y, "y")
+        N, Ts = x.shape
+        dev = x.device
+        if first_noise is not None:
+            first_noise = _dev64(first_noise.reshape(N, self.K), "first_noise")
+        quad = torch.empty((N, self.K), dtype=torch.float64, device=dev)
+        logdet = torch.empty((N, self.K), dtype=torch.float64, device=dev) if want_logdet else None
+        info = torch.zeros((N, self.K), dtype=torch.int32, device=dev) if want_info else None
+        _ffi.check(_ffi.lib.hgp_loglik_pairs_f64(self._h, _ptr(x), _ptr(y), N, Ts, _ptr(first_noise), _ptr(quad),
+                                                 _ptr(logdet), _ptr(info), _stream()), "loglik_pairs")
+        return quad, logdet, info
+
+    def score(self, x, y, first_noise=None):
+        """The reference's score: -0.5 quad - 0.5 Ts log(2 pi)  (GPI_model.py:285, no log-determinant)."""
+        quad, _, info = self.loglik(x, y, first_noise, want_logdet=False)
+        return -0.5 * quad - 0.5 * x.shape[1] * LOG2PI, info
+
+    def close(self):
+        if self._h:
+            _ffi.lib.hgp_pairs_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

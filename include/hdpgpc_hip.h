@@ -1,0 +1,97 @@
+/* hdpgpc_hip.h - C-ABI of libhdpgpc_hip.so: the GP-emission hot path of HDP-GPC on MI355X (gfx950).
+ *
+ * The reference (AdrianPerezHerrero/HDP-GPC) is pure Python and has no FFI layer; every entry point
+ * below replaces the NumPy/SciPy/torch-CPU arithmetic of one Python method (cited per function, paths
+ * relative to the reference's hdpgpc/hdpgpc/).  INTEGRATION.md shows the ctypes binding a maintainer
+ * would add on the reference side.
+ *
+ * Conventions
+ *  - every `const double*` / `double*` / `int32_t*` argument is a DEVICE pointer owned by the caller unless
+ *    its name ends in `_host`; nothing is allocated, freed or synchronised inside a call;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - return value: 0 = work enqueued; -1 = bad argument; -2 = size not supported by this build;
+ *    >= 1000 = 1000 + hipError_t of a failed launch;
+ *  - numerical failure is reported per item in an `info` array (LAPACK convention: 0 = ok, j > 0 = the
+ *    j-th pivot was not positive), so the Python layer can raise torch.linalg.LinAlgError exactly where
+ *    torch.linalg.cholesky would;
+ *  - all arithmetic is fp64; matrices are row-major and dense.
+ */
+#ifndef HDPGPC_HIP_H
+#define HDPGPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGP_ABI_VERSION 1
+/* largest T (basis length) and T* (segment length) served by the register-resident wave kernels */
+#define HGP_MAX_T_WAVE 128
+
+int hgp_abi_version(void);
+
+/* diagnostics: C[16,16] = A[16,16] B[16,16] by one wave through v_mfma_f64_16x16x4_f64, using the operand
+ * and accumulator lane maps the kernels assume (tests/test_gpu_parity.py checks it with asymmetric data). */
+int hgp_debug_mfma_f64(const double* A, const double* B, double* C, void* stream);
+
+/* a1 - (ConstantKernel(c) * RBF(ell) + WhiteKernel(noise))(X, Y)   [scikit-learn kernels.py; built at
+ * GPI_HDP.py:164-166, called at GPI.py:54-58,124,126,474-476].  y == NULL is the one-argument call
+ * (white noise on the diagonal, exact c on the diagonal); otherwise no white noise.  K_out: [nx, ny]. */
+int hgp_gram_rbf_f64(const double* x, int nx, const double* y, int ny, double c, double ell, double noise,
+                     double* K_out, void* stream);
+
+/* a3 - GPI_model._chol_spd (GPI_model.py:83-87), batched: for each of the b matrices A[T,T] (in place)
+ *   L = chol(0.5 (A + A^T) + (add_diag + jitter_rel * max(mean_i |A_ii + add_diag|, eps)) I), lower, zeros above.
+ * Optional outputs (may be NULL): Linv[b,T,T] = L^{-1}; logdet[b] = log det of the regularised matrix. */
+int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add_diag, double* Linv,
+                          double* logdet, int32_t* info, void* stream);
+
+/* a4 + a6 - GPI_model._gaussian_score_shared_cov (GPI_model.py:92-113) over the groups that
+ * GPI_model.compute_sq_err_all builds on a shared grid (GPI_model.py:516-533).
+ * Work item g (one per group chunk) scores `item_cnt[g]` segments against one state:
+ *     S    = Sigma + item_mat[g] * sigma_stride          (T x T, leading dimension T)
+ *     m    = mean  + item_mat[g] * mean_stride           (T)           (mean == NULL: zero mean)
+ *     cov  = 0.5 (S + S^T) + item_add[g] I               ("first" inflation, GPI_model.py:527-529)
+ *     cov += jitter_rel * max(mean |diag cov|, eps) I    (a3)
+ *   for j < item_cnt[g]:  n = seg_ids ? seg_ids[item_off[g] + j] : item_off[g] + j
+ *     out_quad[n]   = (Y[n] - m)^T cov^{-1} (Y[n] - m)
+ *     out_logdet[n] = log det cov          (may be NULL; the reference's score omits it, GPI_model.py:113)
+ *     out_info[n]   = LAPACK info of cov   (may be NULL)
+ * The reference's score is -0.5 * out_quad - 0.5 * T * log(2 pi). */
+int hgp_score_groups_f64(const double* Y, int ldy, const double* mean, long mean_stride, const double* Sigma,
+                         long sigma_stride, int T, const int32_t* item_mat, const double* item_add,
+                         const int32_t* item_off, const int32_t* item_cnt, int n_items, const int32_t* seg_ids,
+                         double jitter_rel, double* out_quad, double* out_logdet, int32_t* out_info, void* stream);
+
+/* a2 + a5 - the per-(segment, cluster) general path: IterativeGaussianProcess.pred_dist (GPI.py:457-503)
+ * followed by the score of GPI_model.log_sq_error (GPI_model.py:250-286), for an N x K batch.
+ *
+ * A plan holds what depends only on the clusters.  theta_host[K,3] = (c, ell, noise) per cluster lives on
+ * the HOST (the reference keeps it in scikit-learn kernel objects); Ts_max is the longest segment the plan will
+ * be asked to score; dev_buf is caller-owned device scratch of at least
+ * hgp_pairs_plan_device_bytes(T, Ts_max, K) bytes and must outlive the plan. */
+typedef struct hgp_pairs_plan hgp_pairs_plan;
+size_t hgp_pairs_plan_device_bytes(int T, int Ts_max, int K);
+int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const double* theta_host, void* dev_buf,
+                          size_t dev_bytes);
+void hgp_pairs_plan_destroy(hgp_pairs_plan* plan);
+/* (Re)compute the per-cluster operators from the current state: x_basis[T], mean[K,T] (= C f, the prior mean
+ * on the basis grid), Sigma[K,T,T].  Per cluster: K~ = ker(xb,xb) + 1e-4 max(mean|diag Sigma|, eps) I
+ * (GPI.py:474,488-489), its Cholesky inverse, and M = c^2 (K~^{-1} Sigma K~^{-1} - K~^{-1}) so that
+ * cov_f = K** + E^T M E  (GPI.py:500) with E = exp(-0.5 ((xb_i - x_j)/ell)^2).  info[K]: Cholesky status. */
+int hgp_pairs_plan_update(hgp_pairs_plan* plan, const double* x_basis, const double* mean, const double* Sigma,
+                          int32_t* info, void* stream);
+/* x[N,Ts], y[N,Ts]: segment grids and values.  first_noise[N,K] (may be NULL): additive diagonal of the
+ * `first` branch (GPI_model.py:271-273).  Outputs [N,K]: out_quad = d^T cov^{-1} d, out_logdet (may be NULL),
+ * out_info (may be NULL).  cov carries the reference's regularisation: +1e-6 I (GPI.py:501, dense Sigma only),
+ * + first_noise, + 1e-8 mean|diag| I (GPI_model.py:83-87). */
+int hgp_loglik_pairs_f64(const hgp_pairs_plan* plan, const double* x, const double* y, int N, int Ts,
+                         const double* first_noise, double* out_quad, double* out_logdet, int32_t* out_info,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDPGPC_HIP_H */

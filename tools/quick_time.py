@@ -1,0 +1,31 @@
+"""Scratch timing of the main kernels on one GPU (not the bench contract - see bench.py)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from hdpgpc_amd import ops
+from oracle import hdpgpc_oracle as orc
+
+def dev(a): return torch.as_tensor(a, dtype=torch.float64, device="cuda")
+
+def timeit(fn, n=5, w=2):
+    for _ in range(w): fn()
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter()-t)/n
+
+for (N,K,T) in [(2048,8,128),(2048,8,96),(256,8,64)]:
+    b = orc.synthetic_batch(N,K,T)
+    plan = ops.PairsPlan(T,T,b["theta"])
+    xb,mean,Sig,x,y = dev(b["xb"]),dev(b["mean"]),dev(b["Sigma"]),dev(b["x"]),dev(b["y"])
+    tu = timeit(lambda: plan.update(xb,mean,Sig))
+    tp = timeit(lambda: plan.loglik(x,y))
+    print(f"pairs N={N} K={K} T={T}: update {tu*1e3:.3f} ms, pairs {tp*1e3:.3f} ms -> {N*K/(tu+tp):.3e} evals/s", flush=True)
+
+for (S,T) in [(4096,128),(4096,90),(4096,64)]:
+    rng=np.random.default_rng(0)
+    Q=rng.normal(size=(64,T,T)); A=Q@Q.transpose(0,2,1)/T+np.eye(T)
+    Sig=dev(np.tile(A,(S//64,1,1))); Y=dev(rng.normal(size=(S,T))); mean=dev(rng.normal(size=(S,T)))
+    items=ops.build_items(list(range(S)),[0.0]*S,[1]*S)
+    items=[dev(i).to(torch.int32) if i.dtype!=np.float64 else dev(i) for i in items]
+    t=timeit(lambda: ops.score_groups(Y,mean,Sig,*items))
+    print(f"score_groups S={S} T={T}: {t*1e3:.3f} ms -> {S/t:.3e} evals/s, {S*T*T*8/t/1e9:.1f} GB/s", flush=True)
