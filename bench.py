@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py - GP log-lik evals/sec of the GP-emission hot path on N MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic segments:
+    per-cluster operators from the current cluster state (hgp_pairs_plan_update)
+  + the N x K per-(segment, cluster) evaluation: Gram build -> Cholesky factor/solve -> Gaussian score
+    (hgp_loglik_pairs_f64), inputs resident in HBM
+  + for N_gpus > 1: one RCCL all-gather of the [N, K] score rows back to every rank (the sampler's view).
+Workload at 1 GPU = BASELINE.json configs[1]: 2 048 segments x 8 clusters, T = 128, fp64, irregular
+segment grids (the general path of pred_dist).  Segments shard across ranks with the per-GPU batch fixed
+(weak scaling); cluster state is replicated.
+
+Prints ONE JSON line (rank 0).  Run: python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with
+python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix (= vector) peak, AMD datasheet; SURVEY.md 8(d)
+N_SEG, K_CL, T_LEN = 2048, 8, 128
+
+
+def algorithmic_flops_per_eval(T):
+    """SURVEY.md 8(d), primary path: Cholesky + two triangular solves + one exp per Gram entry."""
+    return T ** 3 / 3.0 + 3.0 * T ** 2
+
+
+def cpu_baseline(batch, budget_s=12.0):
+    """The oracle (NumPy/SciPy restatement of the reference's per-pair path) on the host cores, bounded sample."""
+    from oracle import hdpgpc_oracle as orc
+    t0 = time.perf_counter()
+    done = 0
+    n = 0
+    while time.perf_counter() - t0 < budget_s and n < batch["x"].shape[0]:
+        orc.loglik_pairs(batch["x"][n:n + 1], batch["y"][n:n + 1], batch["xb"], batch["theta"], batch["mean"], batch["Sigma"])
+        done += batch["theta"].shape[0]
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "evals/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": f"{done} evals ({n} segments x {batch['theta'].shape[0]} clusters, T={batch['x'].shape[1]}) "
+                      f"of the same workload in {dt:.1f} s; NumPy/SciPy oracle, BLAS threads = all host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from hdpgpc_amd import ops
+    from oracle import hdpgpc_oracle as orc   # synthetic workload generator only; never in the timed path
+
+    batch = orc.synthetic_batch(N_SEG, K_CL, T_LEN, seed=20260703 + rank)
+    cl = orc.synthetic_batch(1, K_CL, T_LEN, seed=20260703)          # cluster state is replicated: same on every rank
+    for k in ("xb", "theta", "mean", "Sigma"):
+        batch[k] = cl[k]
+    d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
+    xb, mean, Sig, x, y = d(batch["xb"]), d(batch["mean"]), d(batch["Sigma"]), d(batch["x"]), d(batch["y"])
+    plan = ops.PairsPlan(T_LEN, T_LEN, batch["theta"], device=dev)
+    q_all = torch.empty((world * N_SEG, K_CL), dtype=torch.float64, device=dev) if world > 1 else None
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        plan.update(xb, mean, Sig)
+        if i is not None:
+            ev0[i].record()
+        quad, _, info = plan.loglik(x, y, want_logdet=False)
+        if i is not None:
+            ev1[i].record()
+        score = -0.5 * quad - 0.5 * T_LEN * ops.LOG2PI
+        if world > 1:
+            dist.all_gather_into_tensor(q_all, score)
+            return q_all, info
+        return score, info
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out, info = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert int(info.abs().max()) == 0 and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        evals = world * N_SEG * K_CL * args.steps
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        flops = N_SEG * K_CL * algorithmic_flops_per_eval(T_LEN)
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pairs_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        res = {
+            "metric": "GP log-lik evals/sec (NxK batch, T-point segments)",
+            "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic 2048 segments x 8 clusters per GPU, T=128, fp64, "
+                                   "irregular segment grids (per-pair Gram + Cholesky + score)",
+                       "segments_per_gpu": N_SEG, "clusters": K_CL, "T": T_LEN,
+                       "sharding": f"segments x{world}, 1 RCCL all-gather of scores" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "k_pairs<8>", "kernel_ms": kern_ms,
+                         "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T_LEN)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(batch)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

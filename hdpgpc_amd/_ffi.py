@@ -28,6 +28,7 @@ def _load():
         "hgp_pairs_plan_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, ctypes.POINTER(f64), vp, sz]),
         "hgp_pairs_plan_destroy": (None, [vp]),
         "hgp_pairs_plan_update": (i32, [vp, vp, vp, vp, vp, vp]),
+        "hgp_pairs_plan_scalars": (vp, [vp]),
         "hgp_loglik_pairs_f64": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():

@@ -59,6 +59,8 @@ struct PotrfArgs {
   double* Linv;
   double* logdet;
   int32_t* info;
+  double* minpiv;      // optional, stride minpiv_stride doubles per matrix
+  int minpiv_stride;
 };
 
 template <int NB>
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_potrf(PotrfArgs a) {
   }
   PivotAcc pa;
   pa.init();
-  wave_factor<NB, false>(U, R, scr, Wl, lane, pa, A, T, T);
+  wave_factor<NB, 0>(U, R, scr, Wl, nullptr, lane, pa, A, T, T);
   // zero the strictly upper blocks of the in-place result (torch.linalg.cholesky returns zeros there)
 #pragma unroll
   for (int I = 0; I < NB; ++I)
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_potrf(PotrfArgs a) {
   if (lane == 0) {
     if (a.info) a.info[m] = pa.info;
     if (a.logdet) a.logdet[m] = pa.logdet();
+    if (a.minpiv) a.minpiv[(size_t)m * a.minpiv_stride] = pa.minpiv;
   }
   if (a.Linv) {
     double* Z = a.Linv + (size_t)m * T * T;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_score(ScoreArgs a) {
         R[K][r] = v;
       }
     if (base == 0) {
-      wave_factor<NB, true>(U, R, scr, cnt > 16 ? Wl : nullptr, lane, pa, nullptr, 0, T);
+      wave_factor<NB, 1>(U, R, scr, cnt > 16 ? Wl : nullptr, nullptr, lane, pa, nullptr, 0, T);
       ld = pa.logdet();
     } else {
       wave_fwd_solve<NB>(U, Wl, R, lane);
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm16(const double* __restrict_
 }
 
 // ------------------------------------------------------------------ per-cluster operators (plan)
-// scal[k*8 + ..] : 0 c, 1 ell, 2 noise, 3 iso flag, 4 mean(diag Sigma), 5 jitter of K~
+// scal[k*8 + ..] : 0 c, 1 ell, 2 noise, 3 iso flag, 4 mean(diag Sigma), 5 jitter of K~, 6 ||K~^{-1}||_inf
 struct PrepArgs {
   const double* xb;
   const double* mean;
@@ -311,7 +314,7 @@ struct PrepFinalArgs {
   const double* Q;      // Kinv * S * Kinv
   const double* Kinv;
   const double* mean;   // [K,T]
-  const double* scal;
+  double* scal;
   int T, TP;
   double* Mp;           // [K,TP,TP]
   double* ap;           // [K,TP]
@@ -331,12 +334,26 @@ __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
     Mp[idx] = v;
   }
   const double* mu = a.mean + (size_t)k * T;
+  __shared__ double red[256];
+  double rmax = 0.0;
   for (int i = tid; i < TP; i += 256) {
-    double s = 0.0;
+    double s = 0.0, rs = 0.0;
     if (i < T)
-      for (int j = 0; j < T; ++j) s = fma(Ki[(size_t)i * TP + j], mu[j], s);
+      for (int j = 0; j < T; ++j) {
+        const double kij = Ki[(size_t)i * TP + j];
+        s = fma(kij, mu[j], s);
+        rs += fabs(kij);
+      }
     a.ap[(size_t)k * TP + i] = c * s;
+    rmax = fmax(rmax, rs);
   }
+  red[tid] = rmax;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  if (tid == 0) a.scal[8 * k + 6] = red[0];   // ||K~^{-1}||_inf >= ||K~^{-1}||_2
 }
 
 // -------------------------------------------------------------------------------------- a2 + a5
@@ -436,27 +453,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
       continue;
     }
 
-    // cov tiles (upper): K** = c exp(-0.5 (x_i - x_j)^2 / ell^2) + noise I   (one-argument kernel call, GPI.py:476)
+    // cov tiles (upper).  Each tile starts as K** = c exp(-0.5 (x_i - x_j)^2 / ell^2) + noise I (the one-argument
+    // kernel call, GPI.py:476), computed right before the first MFMA that accumulates into it.
     d4 cov[NB * (NB + 1) / 2];
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int J = I; J < NB; ++J)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ln = launder(lane);
-          int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
-          double v = 0.0;
-          if (i < Ts && j < Ts) {
-            double u = xs[i] - xs[j];
-            v = (i == j) ? cc + noise : cc * exp(-0.5 * (u * u));
-          } else if (i == j) {
-            v = 1.0;
-          }
-          cov[tix(I, J, NB)][r] = v;
-          __builtin_amdgcn_sched_barrier(0);   // one exp at a time: interleaving 144 of them explodes the live set
-        }
-
     // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
     // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
     constexpr int NH = NB / 2;
@@ -518,6 +517,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar3[I], b, BJ[I]);
           }
         }
+        if (h == 0) {
+#pragma unroll
+          for (int I = 0; I <= J; ++I) {
+            const int ln = launder(lane);
+            d4 kt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
+              const double u = xs[i] - xs[j];
+              const double e = cc * exp(-0.5 * (u * u));
+              const bool in = (i < Ts) && (j < Ts);
+              kt[r] = (i == j) ? (in ? cc + noise : 1.0) : (in ? e : 0.0);
+            }
+            cov[tix(I, J, NB)] = kt;
+          }
+        }
         // sweep 2: cov[I][J] += E[rows h, I]^T BJ   (B operand = the accumulators of sweep 1, untouched)
 #pragma unroll
         for (int Kt = 0; Kt < NH; ++Kt)
@@ -539,13 +554,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     }
     PivotAcc pa;
     pa.init();
-    d4 R[NB];
-#pragma unroll
-    for (int K = 0; K < NB; ++K)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) R[K][r] = (c == 0) ? dv[16 * K + g + 4 * r] : 0.0;
-    wave_factor<NB, true>(cov, R, scr, nullptr, lane, pa, nullptr, 0, Ts);
-    double q = wave_colnorm2<NB>(R);
+    d4 Rnone[NB];
+    const double q = wave_factor<NB, 2>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
     if (lane == 0) {
       a.out_quad[oidx] = q;
       if (a.out_logdet) a.out_logdet[oidx] = pa.logdet();
@@ -635,7 +645,7 @@ int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add
   if (!A || T <= 0 || b < 0) return -1;
   if (b == 0) return 0;
   if (T > HGP_MAX_T_WAVE) return -2;
-  PotrfArgs a{A, T, b, jitter_rel, add_diag, Linv, logdet, info};
+  PotrfArgs a{A, T, b, jitter_rel, add_diag, Linv, logdet, info, nullptr, 0};
   dim3 grid((b + WAVES - 1) / WAVES), blk(64 * WAVES);
   hipStream_t st = (hipStream_t)stream;
   switch (nb_for(T)) {
@@ -724,6 +734,8 @@ int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const
 
 void hgp_pairs_plan_destroy(hgp_pairs_plan* plan) { delete plan; }
 
+const double* hgp_pairs_plan_scalars(const hgp_pairs_plan* plan) { return plan ? plan->d_scal : nullptr; }
+
 int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double* mean, const double* Sigma,
                           int32_t* info, void* stream) {
   if (!p || !x_basis || !mean || !Sigma) return -1;
@@ -732,7 +744,7 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   PrepArgs pa{x_basis, mean, Sigma, T, TP, K, p->d_theta, p->d_scal, p->d_A, p->d_S, p->d_xb};
   hipLaunchKernelGGL(k_prep_build, dim3(K), dim3(256), 0, st, pa);
   // L = chol(K~) in place, Z = L^{-1}
-  PotrfArgs fa{p->d_A, TP, K, 0.0, 0.0, p->d_Z, nullptr, info};
+  PotrfArgs fa{p->d_A, TP, K, 0.0, 0.0, p->d_Z, nullptr, info, nullptr, 0};
   dim3 fgrid((K + WAVES - 1) / WAVES), blk(64 * WAVES);
   switch (p->NB) {
     case 2: hipLaunchKernelGGL(k_wave_potrf<2>, fgrid, blk, 0, st, fa); break;

@@ -52,12 +52,40 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// sum over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48) with the gfx950 permlane swaps:
+// after v_permlane16_swap(v, v) the two results hold rows (0,0,2,2) and (1,1,3,3) of v; their sum is the
+// xor-16 butterfly.  v_permlane32_swap does the same for the two 32-lane halves.  No LDS crossbar traffic.
+__device__ __forceinline__ double xrow_sum(double v) {
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  double s = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  lo = (unsigned)__double2loint(s);
+  hi = (unsigned)__double2hiint(s);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// 1/sqrt(a) for a > 0 (normal range): v_rsq_f64 seed (about 23 good bits) + two Newton steps; within
+// an ulp or two of 1.0/sqrt(a).  LAPACK's dpotf2 also scales the column by a rounded reciprocal.
+__device__ __forceinline__ double rsqrt_nr(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  const double h = 0.5 * a;
+  double e = fma(-(h * y), y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-(h * y), y, 0.5);
+  y = fma(y, e, y);
+  return y;
+}
+
 // log-determinant accumulator (product of pivots kept as mantissa * 2^ex) + LAPACK-style info
 struct PivotAcc {
   double mant;
+  double minpiv;  // smallest squared pivot u_kk^2 seen (an upper bound of lambda_min)
   int ex;
   int info;  // 0 = ok, j > 0 = pivot j (1-based) was not positive
-  __device__ __forceinline__ void init() { mant = 1.0; ex = 0; info = 0; }
+  __device__ __forceinline__ void init() { mant = 1.0; minpiv = 1.79769313486231570815e308; ex = 0; info = 0; }
   __device__ __forceinline__ void renorm() {
     ex += __builtin_amdgcn_frexp_exp(mant);
     mant = __builtin_amdgcn_frexp_mant(mant);
@@ -101,13 +129,12 @@ __device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAc
     bool okp = piv > 0.0;                                  // NaN compares false
     if (!okp && pa.info == 0) pa.info = col0 + k + 1;
     piv = okp ? piv : 1.0;
-    pa.mant *= __builtin_amdgcn_frexp_mant(piv);
-    pa.ex += __builtin_amdgcn_frexp_exp(piv);
-    double rinv = 1.0 / sqrt(piv);
-    v[k] = acc * rinv;
+    pa.minpiv = fmin(pa.minpiv, piv);
+    pa.mant *= piv;
+    if ((k & 3) == 3) pa.renorm();       // four pivots between renormalisations: no over/underflow for |log2 piv| < 250
+    v[k] = acc * rsqrt_nr(piv);
     __builtin_amdgcn_sched_barrier(0);   // keep step k's broadcasts next to their FMAs
   }
-  pa.renorm();
   if (Lout != nullptr && lane < 16 && lane < nvalid) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -133,9 +160,14 @@ __device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAc
 // Wlds != nullptr, in which case they are kept in LDS ([K][s][lane]) for later wave_fwd_solve calls.
 // If Lout != nullptr the lower factor L = U^T is written row-major (ld = ldl) for rows/cols < n.
 // ---------------------------------------------------------------------------------------------
-template <int NB, bool RHS>
-__device__ __forceinline__ void wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[NB], double* scr, double* Wlds,
-                                            int lane_in, PivotAcc& pa, double* Lout, int ldl, int n) {
+// RHSMODE: 0 = none; 1 = one block column of 16 right-hand sides as MFMA tiles R[K]; 2 = ONE right-hand side kept
+// as a vector in LDS (dvec[16 NB], per wave) and eliminated on the VALU next to the MFMA stream: on exit dvec
+// holds z = L^{-1} d and the return value is z^T z (valid in every lane).
+template <int NB, int RHSMODE>
+__device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[NB], double* scr, double* Wlds,
+                                              double* dvec, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n) {
+  constexpr bool RHS = (RHSMODE == 1);
+  double zq = 0.0;
 #pragma unroll
   for (int K = 0; K < NB; ++K) {
     const int lane = launder(lane_in);
@@ -145,6 +177,18 @@ __device__ __forceinline__ void wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[
     if (Wlds != nullptr) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) Wlds[(K * 4 + s) * 64 + lane] = W[s];
+    }
+    if (RHSMODE == 2) {   // z_K = W d_K : lane (g,c) sums W[c][4s+g] d[4s+g] over s, rows are summed over g
+      double p = 0.0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) p = fma(W[s], dvec[16 * K + 4 * s + g], p);
+      p = xrow_sum(p);
+      __builtin_amdgcn_wave_barrier();
+      if (g == 0) {
+        dvec[16 * K + c] = p;
+        zq = fma(p, p, zq);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     // panel: U_KJ = U_KK^{-T} A_KJ = W * A_KJ  for J > K, and the rhs tile (J == NB); two tiles in flight
 #pragma unroll
@@ -173,6 +217,20 @@ __device__ __forceinline__ void wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[
         }
       }
     }
+    if (RHSMODE == 2 && K + 1 < NB) {   // d_I -= U_KI^T z_K for I > K
+      double zr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zr[r] = dvec[16 * K + g + 4 * r];
+#pragma unroll
+      for (int I = K + 1; I < NB; ++I) {
+        double q = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q = fma(U[tix(K, I, NB)][r], zr[r], q);
+        q = xrow_sum(q);
+        if (g == 0) dvec[16 * I + c] -= q;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     // trailing update: A_IJ -= U_KI^T U_KJ  for K < I <= J  (and the rhs tiles I > K)
 #pragma unroll
     for (int I = K + 1; I < NB; ++I) {
@@ -185,6 +243,7 @@ __device__ __forceinline__ void wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[
       }
     }
   }
+  return (RHSMODE == 2) ? wave_sum(zq) : 0.0;
 }
 
 // Forward substitution  L Z = R  (L = U^T) on one more block column of 16 right-hand sides, with the

@@ -143,6 +143,18 @@ class PairsPlan:
                                                   _stream()), "pairs_plan_update")
         return self
 
+    def scalars(self):
+        """[K,8] device view: c, ell, noise, iso flag, mean diag Sigma, jitter, ||K~^-1||_inf, 0."""
+        base = _ffi.lib.hgp_pairs_plan_scalars(self._h)
+        off = base - self._buf.data_ptr()
+        return self._buf[off:off + self.K * 64].view(torch.float64).view(self.K, 8)
+
+    def accuracy_bound(self):
+        """eps * (c ||K~^-1||_inf)^2 per cluster: growth of the rounding error of the explicit-operator evaluation
+        relative to the reference's triangular solves (host sync).  ~1e-10 at the reference's length-scale."""
+        s = self.scalars().cpu().numpy()
+        return np.finfo(np.float64).eps * (s[:, 0] * s[:, 6]) ** 2
+
     def loglik(self, x, y, first_noise=None, want_logdet=True, want_info=True):
         """x, y [N,Ts] -> (quad [N,K], logdet [N,K] or None, info [N,K] or None)."""
         x = _dev64(x, "x")

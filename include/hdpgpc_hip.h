@@ -83,6 +83,12 @@ void hgp_pairs_plan_destroy(hgp_pairs_plan* plan);
  * cov_f = K** + E^T M E  (GPI.py:500) with E = exp(-0.5 ((xb_i - x_j)/ell)^2).  info[K]: Cholesky status. */
 int hgp_pairs_plan_update(hgp_pairs_plan* plan, const double* x_basis, const double* mean, const double* Sigma,
                           int32_t* info, void* stream);
+/* Device pointer to the per-cluster scalars [K,8] written by hgp_pairs_plan_update: c, ell, noise, iso flag
+ * (Sigma iso-diagonal, GPI.py:497), mean(diag Sigma), jitter of K~, kinv = ||K~^{-1}||_inf, 0.
+ * The per-pair kernel evaluates cov_f through the explicit operator M; its rounding error relative to the
+ * reference's triangular solves grows like eps * (c * kinv)^2 (about 1e-10 for the reference's length-scale
+ * 1.2 on a unit-spaced grid, where parity is 1e-11; quickly worse for smoother kernels) - callers check it. */
+const double* hgp_pairs_plan_scalars(const hgp_pairs_plan* plan);
 /* x[N,Ts], y[N,Ts]: segment grids and values.  first_noise[N,K] (may be NULL): additive diagonal of the
  * `first` branch (GPI_model.py:271-273).  Outputs [N,K]: out_quad = d^T cov^{-1} d, out_logdet (may be NULL),
  * out_info (may be NULL).  cov carries the reference's regularisation: +1e-6 I (GPI.py:501, dense Sigma only),

@@ -148,8 +148,8 @@ def test_pairs_iso_and_first_and_mixed_lengthscales():
     T, N, K = 48, 6, 5
     b = orc.synthetic_batch(N, K, T, seed=77)
     b["Sigma"][1] = 1.7 * np.eye(T)                       # iso-diagonal state: GPI.py:497-498 branch
-    b["theta"][3, 1] = 2.5                                # a second length-scale group
-    b["theta"][4, 1] = 2.5
+    b["theta"][3, 1] = 0.9                                # a second length-scale group
+    b["theta"][4, 1] = 0.9
     fn = np.zeros((N, K))
     fn[::2, 0] = 0.03
     fn[1, 1] = 0.5
@@ -186,3 +186,18 @@ def test_pairs_against_reference_irregular_grids(tag):
     plan1 = ops.PairsPlan(T, T, np.asarray(st.theta)[None]).update(dev(st.x_basis), dev(mean_last), dev(st.Sigma[-1][None]))
     s1, _ = plan1.score(dev(x), dev(y))
     assert rel_err(s1.cpu().numpy()[:, 0], g["lse_last"]) < RT_PAIR
+
+
+def test_pairs_accuracy_bound_tracks_conditioning():
+    """The explicit per-cluster operator loses digits when K~ is ill-conditioned; the plan reports a bound."""
+    T, N, K = 48, 4, 2
+    b = orc.synthetic_batch(N, K, T, seed=5)
+    b["theta"][1, 1] = 2.5                                # smooth kernel: cond(K~) ~ 1e7
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    bound = plan.accuracy_bound()
+    assert bound[0] < 1e-8 and bound[1] > 1e-6
+    quad, _, _ = plan.loglik(dev(b["x"]), dev(b["y"]))
+    _, q_ref, _ = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
+    err = np.abs(quad.cpu().numpy() - q_ref) / np.abs(q_ref)
+    assert err[:, 0].max() < RT_PAIR
+    assert err[:, 1].max() < 10 * bound[1]                # the indicator is of the right order
