@@ -376,29 +376,37 @@ struct PairsArgs {
   int32_t* out_info;
 };
 
+// Entries of E = exp(-h) and of K** / c with h > PAIRS_CUT (value < 1e-36) are dropped block-wise: a 16x16 block
+// whose entries are ALL below that is neither built nor multiplied.  What is dropped changes a covariance entry by
+// less than 2 T max|M'| 1e-36, far below one ulp; with the reference's length-scale 1.2 on a unit-spaced grid only
+// the blocks |Kt - J| <= 1 survive, which removes ~60 % of the MFMA work at T = 128.  The decision is taken from the
+// data (any grid), never from an assumed band structure.
+constexpr double PAIRS_CUT = 82.9;
+
 template <int NB>
 constexpr size_t pairs_lds_bytes() {
-  return sizeof(double) * ((size_t)(16 * NB) * (16 * NB) + 3 * 16 * NB + WAVES * DIAG_SCR + WAVES * 16 * NB);
+  return sizeof(double) * ((size_t)(16 * NB) * (16 * NB) + 3 * 16 * NB + WAVES * DIAG_SCR + WAVES * 16 * NB) +
+         sizeof(int) * 16;
 }
 
 // One workgroup per segment n; its 4 waves take the clusters of the length-scale group round-robin.
-// E_n = exp(-0.5 ((xb_k - x_j)/ell)^2) is built once per workgroup in LDS and shared by the waves; each
-// wave then evaluates one (segment, cluster) pair entirely in its own registers:
-//   cov = c R_n + noise I + E^T M'_k E   (two MFMA GEMM sweeps, the first result feeding the second
-//   straight from the accumulators), regularise, factor, forward-solve, reduce.
+// E_n = exp(-0.5 ((xb_k - x_j)/ell)^2) is built once per workgroup in LDS (active 16x16 blocks only) and shared by
+// the waves; each wave then evaluates one (segment, cluster) pair entirely in its own registers:
+//   cov = c R_n + noise I + E^T M'_k E   (two MFMA sweeps per column panel, the first result feeding the second
+//   straight from its accumulators), regularise, factor (wave_factor), eliminate d on the VALU, reduce.
 template <int NB>
 __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   constexpr int TP = 16 * NB;
-  constexpr int NS = TP / 4;
+  constexpr int NH = NB / 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* E = smem;               // [TP][TP]: row k = basis point, column j = segment point
   double* xs = E + TP * TP;       // segment grid / ell
   double* ys = xs + TP;
   double* xbs = ys + TP;          // basis grid / ell
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int g = lane >> 4, c = lane & 15;
+  const int tid = threadIdx.x, wave = tid >> 6;
   double* scr = xbs + TP + wave * DIAG_SCR;
   double* dv = xbs + TP + WAVES * DIAG_SCR + wave * TP;
+  int* amask = reinterpret_cast<int*>(xbs + TP + WAVES * DIAG_SCR + WAVES * TP);   // bit Kt of amask[J]: block (Kt, J) of E active
   const int n = blockIdx.x;
   const int T = a.T, Ts = a.Ts;
 
@@ -407,15 +415,31 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
     xbs[i] = (i < T) ? a.xb[i] / a.ell : 0.0;
   }
+  if (tid < 16) amask[tid] = 0;
   __syncthreads();
-  for (int idx = tid; idx < TP * TP; idx += 64 * WAVES) {
-    int k = idx / TP, j = idx % TP;
-    double v = 0.0;
-    if (k < T && j < Ts) {
-      double u = xbs[k] - xs[j];
-      v = exp(-0.5 * (u * u));
+  {
+    const int lane = tid & 63, g = lane >> 4, c = lane & 15;
+    for (int blk = wave; blk < NB * NB; blk += WAVES) {
+      const int Kt = blk / NB, Jb = blk % NB;
+      const int j = 16 * Jb + c;
+      double h[4];
+      bool near = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * Kt + g + 4 * r;
+        const double u = xbs[k] - xs[j];
+        h[r] = 0.5 * (u * u);
+        near = near || (k < T && j < Ts && h[r] < PAIRS_CUT);
+      }
+      if (__any(near)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * Kt + g + 4 * r;
+          E[k * TP + j] = (k < T && j < Ts) ? exp(-h[r]) : 0.0;
+        }
+        if (lane == 0) atomicOr(&amask[Jb], 1 << Kt);
+      }
     }
-    E[idx] = v;
   }
   __syncthreads();
 
@@ -428,16 +452,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     const bool iso = sc[3] != 0.0;
     const double fn = a.first_noise ? a.first_noise[(size_t)n * a.K + kc] : 0.0;
     const size_t oidx = (size_t)n * a.K + kc;
+    int msk[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) msk[J] = __builtin_amdgcn_readfirstlane(amask[J]);
 
-    // d = y - E^T a'   (a' = c K~^{-1} mean)
+    // d = y - E^T a'   (a' = c K~^{-1} mean), column block by column block over the active blocks of E
     const double* apk = a.ap + (size_t)kc * TP;
     double dsq = 0.0;
-    for (int j = lane; j < TP; j += 64) {
-      double f = 0.0;
-      for (int k = 0; k < T; ++k) f = fma(E[k * TP + j], apk[k], f);
-      double d = (j < Ts) ? ys[j] - f : 0.0;
-      dv[j] = d;
-      dsq = fma(d, d, dsq);
+#pragma unroll
+    for (int Jb = 0; Jb < NB; ++Jb) {
+      double p = 0.0;
+#pragma unroll
+      for (int Kt = 0; Kt < NB; ++Kt) {
+        if (msk[Jb] & (1 << Kt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p = fma(E[(16 * Kt + g + 4 * r) * TP + 16 * Jb + c], apk[16 * Kt + g + 4 * r], p);
+        }
+      }
+      p = xrow_sum(p);
+      if (g == 0) {
+        const int j = 16 * Jb + c;
+        const double d = (j < Ts) ? ys[j] - p : 0.0;
+        dv[j] = d;
+        dsq = fma(d, d, dsq);
+      }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -458,63 +496,61 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     d4 cov[NB * (NB + 1) / 2];
     // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
     // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
-    constexpr int NH = NB / 2;
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
       const double* Ej = E + g * TP + 16 * J + c;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        // sweep 1: BJ = M'[16 NH h .. , :] E[:, J]; M' is symmetric, so row-tile I of the A operand is read as
-        // M'[k][16 I + c]: 128 contiguous bytes per 16 lanes.  4-deep register ring over the k-steps.
+        // sweep 1: BJ = M'[16 NH h .. , :] E[:, J] over the ACTIVE k-blocks of column panel J.  M' is symmetric, so
+        // row-tile I of the A operand is read as M'[k][16 I + c]: 128 contiguous bytes per 16 lanes, from L2.
+        // Double-buffered at block granularity: 4 k-steps x NH tiles of MFMA cover the next block's 4 NH loads.
         const double* Mk = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP + 16 * NH * h + c;
         d4 BJ[NH];
 #pragma unroll
         for (int I = 0; I < NH; ++I) BJ[I] = (d4){0.0, 0.0, 0.0, 0.0};
-        double ar0[NH], ar1[NH], ar2[NH], ar3[NH];
+        double b0[4][NH], b1[4][NH];
+        int m = msk[J];
+        int k0 = -1, k1 = -1;
+        if (m) {
+          k0 = __builtin_ctz(m);
+          m &= m - 1;
 #pragma unroll
-        for (int I = 0; I < NH; ++I) {
-          ar0[I] = Mk[16 * I];
-          ar1[I] = Mk[(size_t)4 * TP + 16 * I];
-          ar2[I] = Mk[(size_t)8 * TP + 16 * I];
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int I = 0; I < NH; ++I) b0[s][I] = Mk[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
         }
 #pragma nounroll
-        for (int s = 0; s < NS; s += 4) {
-          const double* Ms = Mk + (size_t)4 * s * TP;
-          const double* Es = Ej + (size_t)4 * s * TP;
-          {
+        while (k0 >= 0) {
+          k1 = -1;
+          if (m) {
+            k1 = __builtin_ctz(m);
+            m &= m - 1;
 #pragma unroll
-            for (int I = 0; I < NH; ++I) ar3[I] = Ms[(size_t)12 * TP + 16 * I];
-            double b = Es[0];
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar0[I], b, BJ[I]);
+              for (int I = 0; I < NH; ++I) b1[s][I] = Mk[(size_t)(16 * k1 + 4 * s) * TP + 16 * I];
           }
-          const bool more = s + 4 < NS;
-          {
-            if (more) {
 #pragma unroll
-              for (int I = 0; I < NH; ++I) ar0[I] = Ms[(size_t)16 * TP + 16 * I];
-            }
-            double b = Es[4 * TP];
+          for (int s = 0; s < 4; ++s) {
+            const double b = Ej[(16 * k0 + 4 * s) * TP];
 #pragma unroll
-            for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar1[I], b, BJ[I]);
+            for (int I = 0; I < NH; ++I) BJ[I] = mfma(b0[s][I], b, BJ[I]);
           }
-          {
-            if (more) {
+          if (k1 < 0) break;
+          k0 = -1;
+          if (m) {
+            k0 = __builtin_ctz(m);
+            m &= m - 1;
 #pragma unroll
-              for (int I = 0; I < NH; ++I) ar1[I] = Ms[(size_t)20 * TP + 16 * I];
-            }
-            double b = Es[8 * TP];
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar2[I], b, BJ[I]);
+              for (int I = 0; I < NH; ++I) b0[s][I] = Mk[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
           }
-          {
-            if (more) {
 #pragma unroll
-              for (int I = 0; I < NH; ++I) ar2[I] = Ms[(size_t)24 * TP + 16 * I];
-            }
-            double b = Es[12 * TP];
+          for (int s = 0; s < 4; ++s) {
+            const double b = Ej[(16 * k1 + 4 * s) * TP];
 #pragma unroll
-            for (int I = 0; I < NH; ++I) BJ[I] = mfma(ar3[I], b, BJ[I]);
+            for (int I = 0; I < NH; ++I) BJ[I] = mfma(b1[s][I], b, BJ[I]);
           }
         }
         if (h == 0) {
@@ -522,26 +558,48 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
           for (int I = 0; I <= J; ++I) {
             const int ln = launder(lane);
             d4 kt;
+            double hh[4];
+            bool near = false;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
               const double u = xs[i] - xs[j];
-              const double e = cc * exp(-0.5 * (u * u));
-              const bool in = (i < Ts) && (j < Ts);
-              kt[r] = (i == j) ? (in ? cc + noise : 1.0) : (in ? e : 0.0);
+              hh[r] = 0.5 * (u * u);
+              near = near || (i < Ts && j < Ts && hh[r] < PAIRS_CUT);
+            }
+            if (__any(near)) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
+                const double e = cc * exp(-hh[r]);
+                const bool in = (i < Ts) && (j < Ts);
+                kt[r] = (i == j) ? (in ? cc + noise : 1.0) : (in ? e : 0.0);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
+                kt[r] = (i == j) ? 1.0 : 0.0;    // only reachable for padded diagonal tiles
+              }
             }
             cov[tix(I, J, NB)] = kt;
           }
         }
-        // sweep 2: cov[I][J] += E[rows h, I]^T BJ   (B operand = the accumulators of sweep 1, untouched)
+        // sweep 2: cov[I][J] += E[rows h, I]^T BJ over the active blocks (Kt, I) of E; the B operand is the
+        // accumulator of sweep 1, untouched.
 #pragma unroll
-        for (int Kt = 0; Kt < NH; ++Kt)
+        for (int Kt = 0; Kt < NH; ++Kt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double* Er = E + (16 * (NH * h + Kt) + 4 * r + g) * TP + c;
+          for (int I = 0; I <= J; ++I) {
+            if (msk[I] & (1 << (NH * h + Kt))) {
 #pragma unroll
-            for (int I = 0; I <= J; ++I) cov[tix(I, J, NB)] = mfma(Er[16 * I], BJ[Kt][r], cov[tix(I, J, NB)]);
+              for (int r = 0; r < 4; ++r) {
+                const double* Er = E + (16 * (NH * h + Kt) + 4 * r + g) * TP + c;
+                cov[tix(I, J, NB)] = mfma(Er[16 * I], BJ[Kt][r], cov[tix(I, J, NB)]);
+              }
+            }
           }
+        }
       }
     }
 

@@ -201,3 +201,23 @@ def test_pairs_accuracy_bound_tracks_conditioning():
     err = np.abs(quad.cpu().numpy() - q_ref) / np.abs(q_ref)
     assert err[:, 0].max() < RT_PAIR
     assert err[:, 1].max() < 10 * bound[1]                # the indicator is of the right order
+
+
+def test_pairs_block_skipping_on_arbitrary_grids():
+    """The kernel drops 16x16 blocks of the cross-Gram whose entries are all < 1e-36; the decision is taken
+    from the data, so shifted, reversed, permuted and far-away grids must all agree with the oracle."""
+    T, K = 64, 3
+    b = orc.synthetic_batch(6, K, T, seed=31)
+    rng = np.random.default_rng(3)
+    x = b["x"].copy()
+    x[1] = x[1] + 37.5                      # shifted: most blocks inactive, band off the diagonal
+    x[2] = x[2][::-1].copy()                # reversed: anti-diagonal band
+    x[3] = rng.permutation(x[3])            # permuted: no band structure at all
+    x[4] = x[4] + 500.0                     # far away: every block of E inactive (cov = K** only)
+    x[5] = np.linspace(10.0, 20.0, T)       # dense cluster of points: few wide active blocks
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    quad, logdet, info = plan.loglik(dev(x), dev(b["y"]))
+    assert int(info.abs().max()) == 0
+    _, q_ref, ld_ref = orc.loglik_pairs(x, b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
+    assert rel_err(quad.cpu().numpy(), q_ref) < RT_PAIR
+    assert rel_err(logdet.cpu().numpy(), ld_ref) < RT_PAIR
