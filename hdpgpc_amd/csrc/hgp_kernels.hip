@@ -59,8 +59,6 @@ struct PotrfArgs {
   double* Linv;
   double* logdet;
   int32_t* info;
-  double* minpiv;      // optional, stride minpiv_stride doubles per matrix
-  int minpiv_stride;
 };
 
 template <int NB>
@@ -101,7 +99,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_potrf(PotrfArgs a) {
   if (lane == 0) {
     if (a.info) a.info[m] = pa.info;
     if (a.logdet) a.logdet[m] = pa.logdet();
-    if (a.minpiv) a.minpiv[(size_t)m * a.minpiv_stride] = pa.minpiv;
   }
   if (a.Linv) {
     double* Z = a.Linv + (size_t)m * T * T;
@@ -410,10 +407,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   const int n = blockIdx.x;
   const int T = a.T, Ts = a.Ts;
 
+  // Padding (i >= Ts, k >= T) uses far-apart sentinels instead of bounds predicates: every kernel entry that
+  // involves a padded point is then exp(-huge) = 0 by itself (all differences stay finite: < 3e152).
   for (int i = tid; i < TP; i += 64 * WAVES) {
-    xs[i] = (i < Ts) ? a.x[(size_t)n * Ts + i] / a.ell : 0.0;
+    xs[i] = (i < Ts) ? a.x[(size_t)n * Ts + i] / a.ell : 1e150 * (double)(1 + i);
     ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
-    xbs[i] = (i < T) ? a.xb[i] / a.ell : 0.0;
+    xbs[i] = (i < T) ? a.xb[i] / a.ell : -1e150 * (double)(1 + i);
   }
   if (tid < 16) amask[tid] = 0;
   __syncthreads();
@@ -429,14 +428,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
         const int k = 16 * Kt + g + 4 * r;
         const double u = xbs[k] - xs[j];
         h[r] = 0.5 * (u * u);
-        near = near || (k < T && j < Ts && h[r] < PAIRS_CUT);
+        near = near || (h[r] < PAIRS_CUT);
       }
       if (__any(near)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * Kt + g + 4 * r;
-          E[k * TP + j] = (k < T && j < Ts) ? exp(-h[r]) : 0.0;
-        }
+        for (int r = 0; r < 4; ++r) E[(16 * Kt + g + 4 * r) * TP + j] = exp(-h[r]);
         if (lane == 0) atomicOr(&amask[Jb], 1 << Kt);
       }
     }
@@ -472,7 +468,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
       p = xrow_sum(p);
       if (g == 0) {
         const int j = 16 * Jb + c;
-        const double d = (j < Ts) ? ys[j] - p : 0.0;
+        const double d = ys[j] - p;     // padded entries: 0 - 0
         dv[j] = d;
         dsq = fma(d, d, dsq);
       }
@@ -562,25 +558,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             bool near = false;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
-              const double u = xs[i] - xs[j];
+              const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
               hh[r] = 0.5 * (u * u);
-              near = near || (i < Ts && j < Ts && hh[r] < PAIRS_CUT);
+              near = near || (hh[r] < PAIRS_CUT);
             }
             if (__any(near)) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
-                const double e = cc * exp(-hh[r]);
-                const bool in = (i < Ts) && (j < Ts);
-                kt[r] = (i == j) ? (in ? cc + noise : 1.0) : (in ? e : 0.0);
-              }
+              for (int r = 0; r < 4; ++r) kt[r] = cc * exp(-hh[r]);
             } else {
+              kt = (d4){0.0, 0.0, 0.0, 0.0};
+            }
+            if (I == J) {   // exact diagonal of the one-argument kernel call; identity on the padding
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int i = 16 * I + (ln >> 4) + 4 * r, j = 16 * J + (ln & 15);
-                kt[r] = (i == j) ? 1.0 : 0.0;    // only reachable for padded diagonal tiles
-              }
+              for (int r = 0; r < 4; ++r)
+                if ((ln >> 4) + 4 * r == (ln & 15)) kt[r] = (16 * I + (ln & 15) < Ts) ? cc + noise : 1.0;
             }
             cov[tix(I, J, NB)] = kt;
           }
@@ -604,11 +595,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     }
 
     // regularisation of the reference: +1e-6 I (GPI.py:501), + first, + 1e-8 mean|diag| I (GPI_model.py:83-87)
-    add_diag<NB>(cov, 1e-6, Ts, lane);
-    if (fn != 0.0) add_diag<NB>(cov, fn, Ts, lane);
     {
-      double dm = diag_abs_mean<NB>(cov, Ts, lane);
-      add_diag<NB>(cov, 1e-8 * fmax(dm, F64_EPS), Ts, lane);
+      const double sh = 1e-6 + fn;
+      const double dm = diag_abs_mean<NB>(cov, Ts, lane, sh);
+      add_diag<NB>(cov, sh + 1e-8 * fmax(dm, F64_EPS), Ts, lane);
     }
     PivotAcc pa;
     pa.init();
@@ -703,7 +693,7 @@ int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add
   if (!A || T <= 0 || b < 0) return -1;
   if (b == 0) return 0;
   if (T > HGP_MAX_T_WAVE) return -2;
-  PotrfArgs a{A, T, b, jitter_rel, add_diag, Linv, logdet, info, nullptr, 0};
+  PotrfArgs a{A, T, b, jitter_rel, add_diag, Linv, logdet, info};
   dim3 grid((b + WAVES - 1) / WAVES), blk(64 * WAVES);
   hipStream_t st = (hipStream_t)stream;
   switch (nb_for(T)) {
@@ -802,7 +792,7 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   PrepArgs pa{x_basis, mean, Sigma, T, TP, K, p->d_theta, p->d_scal, p->d_A, p->d_S, p->d_xb};
   hipLaunchKernelGGL(k_prep_build, dim3(K), dim3(256), 0, st, pa);
   // L = chol(K~) in place, Z = L^{-1}
-  PotrfArgs fa{p->d_A, TP, K, 0.0, 0.0, p->d_Z, nullptr, info, nullptr, 0};
+  PotrfArgs fa{p->d_A, TP, K, 0.0, 0.0, p->d_Z, nullptr, info};
   dim3 fgrid((K + WAVES - 1) / WAVES), blk(64 * WAVES);
   switch (p->NB) {
     case 2: hipLaunchKernelGGL(k_wave_potrf<2>, fgrid, blk, 0, st, fa); break;

@@ -30,6 +30,11 @@ __host__ __device__ constexpr int ntiles(int NB) { return NB * (NB + 1) / 2; }
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// D = C - A B: for the f64 MFMA the blgp field is neg:[a,b,c] (checked on gfx950 with tools/probe_neg.hip),
+// so the trailing updates need no VALU negation of the panel tiles.
+__device__ __forceinline__ d4 mfma_sub(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
 
 // value of lane `src` (compile-time constant after unrolling) broadcast to the whole wave through SGPRs
 __device__ __forceinline__ double lane_bcast(double v, int src) {
@@ -82,10 +87,9 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
 // log-determinant accumulator (product of pivots kept as mantissa * 2^ex) + LAPACK-style info
 struct PivotAcc {
   double mant;
-  double minpiv;  // smallest squared pivot u_kk^2 seen (an upper bound of lambda_min)
   int ex;
   int info;  // 0 = ok, j > 0 = pivot j (1-based) was not positive
-  __device__ __forceinline__ void init() { mant = 1.0; minpiv = 1.79769313486231570815e308; ex = 0; info = 0; }
+  __device__ __forceinline__ void init() { mant = 1.0; ex = 0; info = 0; }
   __device__ __forceinline__ void renorm() {
     ex += __builtin_amdgcn_frexp_exp(mant);
     mant = __builtin_amdgcn_frexp_mant(mant);
@@ -126,11 +130,8 @@ __device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAc
       acc = fma(-s, v[m], acc);
     }
     double piv = lane_bcast(acc, k);                       // u_kk^2
-    bool okp = piv > 0.0;                                  // NaN compares false
-    if (!okp && pa.info == 0) pa.info = col0 + k + 1;
-    piv = okp ? piv : 1.0;
-    pa.minpiv = fmin(pa.minpiv, piv);
-    pa.mant *= piv;
+    if (!(piv > 0.0) && pa.info == 0) pa.info = col0 + k + 1;   // NaN compares false; a bad pivot then poisons
+    pa.mant *= piv;                                             // the outputs with NaN, info says where
     if ((k & 3) == 3) pa.renorm();       // four pivots between renormalisations: no over/underflow for |log2 piv| < 250
     v[k] = acc * rsqrt_nr(piv);
     __builtin_amdgcn_sched_barrier(0);   // keep step k's broadcasts next to their FMAs
@@ -234,12 +235,12 @@ __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R
     // trailing update: A_IJ -= U_KI^T U_KJ  for K < I <= J  (and the rhs tiles I > K)
 #pragma unroll
     for (int I = K + 1; I < NB; ++I) {
-      const d4 nu = -U[tix(K, I, NB)];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int J = I; J < NB; ++J) U[tix(I, J, NB)] = mfma(nu[s], U[tix(K, J, NB)][s], U[tix(I, J, NB)]);
-        if (RHS) R[I] = mfma(nu[s], R[K][s], R[I]);
+        for (int J = I; J < NB; ++J)
+          U[tix(I, J, NB)] = mfma_sub(U[tix(K, I, NB)][s], U[tix(K, J, NB)][s], U[tix(I, J, NB)]);
+        if (RHS) R[I] = mfma_sub(U[tix(K, I, NB)][s], R[K][s], R[I]);
       }
     }
   }
@@ -259,9 +260,8 @@ __device__ __forceinline__ void wave_fwd_solve(const d4 (&U)[NB * (NB + 1) / 2],
 #pragma unroll
     for (int I = 0; I < K; ++I) {
       if (I < K0) continue;
-      const d4 nu = -U[tix(I, K, NB)];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) t = mfma(nu[s], R[I][s], t);     // t -= U_IK^T Z_I
+      for (int s = 0; s < 4; ++s) t = mfma_sub(U[tix(I, K, NB)][s], R[I][s], t);     // t -= U_IK^T Z_I
     }
     d4 z = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -326,9 +326,9 @@ __device__ __forceinline__ void add_diag(d4 (&U)[NB * (NB + 1) / 2], double shif
   }
 }
 
-// mean over i < n of |A_ii| taken from the diagonal tiles
+// mean over i < n of |A_ii + shift| taken from the diagonal tiles
 template <int NB>
-__device__ __forceinline__ double diag_abs_mean(const d4 (&U)[NB * (NB + 1) / 2], int n, int lane_in) {
+__device__ __forceinline__ double diag_abs_mean(const d4 (&U)[NB * (NB + 1) / 2], int n, int lane_in, double shift = 0.0) {
   double s = 0.0;
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
@@ -337,7 +337,7 @@ __device__ __forceinline__ double diag_abs_mean(const d4 (&U)[NB * (NB + 1) / 2]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int i = 16 * I + g + 4 * r;
-      if (g + 4 * r == c && i < n) s += fabs(U[tix(I, I, NB)][r]);
+      if (g + 4 * r == c && i < n) s += fabs(U[tix(I, I, NB)][r] + shift);
     }
   }
   return wave_sum(s) / (double)n;
