@@ -23,13 +23,20 @@ def _load():
         "hgp_debug_mfma_f64": (i32, [vp, vp, vp, vp]),
         "hgp_gram_rbf_f64": (i32, [vp, i32, vp, i32, f64, f64, f64, vp, vp]),
         "hgp_potrf_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, vp]),
-        "hgp_score_groups_f64": (i32, [vp, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i32, vp, f64, vp, vp, vp, vp]),
+        "hgp_score_groups_f64": (i32, [vp, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, f64, vp, vp, vp, vp]),
         "hgp_pairs_plan_device_bytes": (sz, [i32, i32, i32]),
         "hgp_pairs_plan_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, ctypes.POINTER(f64), vp, sz]),
         "hgp_pairs_plan_destroy": (None, [vp]),
         "hgp_pairs_plan_update": (i32, [vp, vp, vp, vp, vp, vp]),
         "hgp_pairs_plan_scalars": (vp, [vp]),
-        "hgp_loglik_pairs_f64": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+        "hgp_loglik_pairs_f64": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "hgp_gemm_batched_f64": (i32, [i32, i32, i32, i32, i32, f64, vp, i32, i64, vp, i32, i64, f64, vp, i32, i64, i32, vp]),
+        "hgp_matrix_lik_ws_bytes": (sz, [i32, i32]),
+        "hgp_lat_error_f64": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
+        "hgp_mniw_loglik_f64": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]),
+        "hgp_warp_cov_f64": (i32, [vp, i32, f64, f64, f64, i32, vp, vp]),
+        "hgp_chol_rank1_f64": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
+        "hgp_trsv_lower_quad_f64": (i32, [vp, i32, vp, i32, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header and library disagree

@@ -129,6 +129,7 @@ struct ScoreArgs {
   long sigma_stride;
   int T;
   const int32_t* item_mat;
+  const int32_t* item_mean;   // optional: row of `mean` per item (default: item_mat)
   const double* item_add;
   const int32_t* item_off;
   const int32_t* item_cnt;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_score(ScoreArgs a) {
   const int T = a.T;
   const int mat = a.item_mat[it];
   const double* S = a.Sigma + (size_t)mat * a.sigma_stride;
-  const double* mu = a.mean ? a.mean + (size_t)mat * a.mean_stride : nullptr;
+  const double* mu = a.mean ? a.mean + (size_t)(a.item_mean ? a.item_mean[it] : mat) * a.mean_stride : nullptr;
   d4 U[NB * (NB + 1) / 2];
   d4 R[NB];
   double* Wl = w_all + wave * NB * 256;
@@ -198,30 +199,185 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_score(ScoreArgs a) {
 }
 
 // --------------------------------------------------------------------------- batched tile GEMM
-// C[b] = op(A[b]) * B[b] on n x n matrices (n a multiple of 16), one wave per 16x16 tile of C.
-// Only used for the per-cluster operators (K matrices per update), never per (segment, cluster).
-template <bool TA>
-__global__ __launch_bounds__(64 * WAVES) void k_gemm16(const double* __restrict__ A, const double* __restrict__ B,
-                                                        double* __restrict__ C, int n) {
+// C[b] = alpha op(A[b]) op(B[b]) + beta C[b], any M x N x Kd, one wave per 16x16 tile of C, operands straight
+// from global memory (L2).  Used for per-cluster operators and for the matrix-valued likelihood terms (a8, a9),
+// never per (segment, cluster) pair.
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int M, N, Kd, lda, ldb, ldc;
+  long sA, sB, sC;
+  double alpha, beta;
+  int tA, tB;
+};
+
+__global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
-  const int nt = n / 16;
+  const int ntn = (a.N + 15) / 16, ntm = (a.M + 15) / 16;
   const int tile = blockIdx.x * WAVES + wave;
-  if (tile >= nt * nt) return;
-  const int ti = tile / nt, tj = tile % nt;
-  const size_t off = (size_t)blockIdx.y * n * n;
-  A += off;
-  B += off;
-  C += off;
+  if (tile >= ntm * ntn) return;
+  const int ti = tile / ntn, tj = tile % ntn;
+  const double* A = a.A + (size_t)blockIdx.y * a.sA;
+  const double* B = a.B + (size_t)blockIdx.y * a.sB;
+  double* C = a.C + (size_t)blockIdx.y * a.sC;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int kk = 0; kk < n / 4; ++kk) {
-    int k = 4 * kk + g;
-    double av = TA ? A[(size_t)k * n + 16 * ti + c] : A[(size_t)(16 * ti + c) * n + k];
-    double bv = B[(size_t)k * n + 16 * tj + c];
+  const int row = 16 * ti + c, col = 16 * tj + c;
+  for (int kk = 0; kk < (a.Kd + 3) / 4; ++kk) {
+    const int k = 4 * kk + g;
+    double av = 0.0, bv = 0.0;
+    if (k < a.Kd) {
+      if (row < a.M) av = a.tA ? A[(size_t)k * a.lda + row] : A[(size_t)row * a.lda + k];
+      if (col < a.N) bv = a.tB ? B[(size_t)col * a.ldb + k] : B[(size_t)k * a.ldb + col];
+    }
     acc = mfma(av, bv, acc);
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) C[(size_t)(16 * ti + g + 4 * r) * n + 16 * tj + c] = acc[r];
+  for (int r = 0; r < 4; ++r) {
+    const int i = 16 * ti + g + 4 * r;
+    if (i < a.M && col < a.N) {
+      double v = a.alpha * acc[r];
+      if (a.beta != 0.0) v += a.beta * C[(size_t)i * a.ldc + col];
+      C[(size_t)i * a.ldc + col] = v;
+    }
+  }
+}
+
+int launch_gemm(const GemmArgs& a, int batch, hipStream_t st) {
+  const int nt = ((a.M + 15) / 16) * ((a.N + 15) / 16);
+  hipLaunchKernelGGL(k_gemm, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
+  return launch_status();
+}
+
+// out[b] = scale * sum_i X[b][i] * Y[b][i]  (+ out[b] if accumulate)
+__global__ __launch_bounds__(256) void k_dot_batched(const double* __restrict__ X, const double* __restrict__ Y, long sX,
+                                                      long sY, long n, double scale, int accumulate, double* out) {
+  __shared__ double red[256];
+  const double* x = X + (size_t)blockIdx.x * sX;
+  const double* y = Y + (size_t)blockIdx.x * sY;
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) s = fma(x[i], y[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = (accumulate ? out[blockIdx.x] : 0.0) + scale * red[0];
+}
+
+// C[b] = A[b] - B[b]  (elementwise, n per item)
+__global__ void k_sub_batched(const double* __restrict__ A, const double* __restrict__ B, long sA, long sB, long n,
+                              double* __restrict__ C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)n) C[(size_t)blockIdx.y * n + i] = A[(size_t)blockIdx.y * sA + i] - B[(size_t)blockIdx.y * sB + i];
+}
+
+// r[b] = f_cur[b] - A[b] f_prev[b]   (a8 residual), one workgroup per item
+__global__ __launch_bounds__(256) void k_lat_resid(const double* __restrict__ f_cur, const double* __restrict__ f_prev,
+                                                    const double* __restrict__ A, int T, double* __restrict__ r) {
+  const int b = blockIdx.x;
+  const double* Ab = A + (size_t)b * T * T;
+  const double* fp = f_prev + (size_t)b * T;
+  for (int i = threadIdx.x; i < T; i += 256) {
+    double s = 0.0;
+    for (int k = 0; k < T; ++k) s = fma(Ab[(size_t)i * T + k], fp[k], s);
+    r[(size_t)b * T + i] = f_cur[(size_t)b * T + i] - s;
+  }
+}
+
+// a11: omega^2 exp(-0.5 dx^2 / rho^2) + diag_add I on the (optionally [0,1]-normalised) grid
+__global__ void k_warp_cov(const double* __restrict__ x, int T, double rho, double omega, double diag_add, int normalize,
+                           double* __restrict__ K) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)T * T) return;
+  const int i = (int)(idx / T), j = (int)(idx % T);
+  double xi = x[i], xj = x[j];
+  if (normalize) {
+    const double x0 = x[0];
+    const double rng = fabs((x[T - 1] - x0) - (x0 - x0)) + 1e-12;   // amtgp_warping_system.py:163-166
+    xi = (xi - x0) / rng;
+    xj = (xj - x0) / rng;
+  }
+  const double dx = xi - xj;
+  double v = (omega * omega) * exp(-0.5 * (dx * dx) / (rho * rho));
+  if (i == j) v += diag_add;
+  K[idx] = v;
+}
+
+// config 5: L <- chol(alpha L L^T + beta v v^T), one wave per matrix (T <= 256), O(T^2) instead of O(T^3).
+// Classic hyperbolic-free update: for k: r = hypot(L_kk, x_k), c = r / L_kk, s = x_k / L_kk, column k and x updated.
+struct Rank1Args {
+  double* L;
+  const double* v;
+  const double* alpha;
+  const double* beta;
+  int T, b;
+  int32_t* info;
+};
+
+__global__ __launch_bounds__(64 * WAVES) void k_chol_rank1(Rank1Args a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WAVES + wave;
+  if (m >= a.b) return;
+  const int T = a.T;
+  double* L = a.L + (size_t)m * T * T;
+  const double al = a.alpha ? a.alpha[m] : 1.0, be = a.beta ? a.beta[m] : 1.0;
+  const double sa = sqrt(al), sb = sqrt(be);
+  double x[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = lane + 64 * q;
+    x[q] = (i < T) ? sb * a.v[(size_t)m * T + i] : 0.0;
+  }
+  int info = (al > 0.0 && be >= 0.0) ? 0 : -1;
+  for (int k = 0; k < T; ++k) {
+    const int kq = k >> 6;
+    const double xsel = (kq == 0) ? x[0] : (kq == 1) ? x[1] : (kq == 2) ? x[2] : x[3];
+    const double xk = __shfl(xsel, k & 63, 64);
+    const double lkk = sa * L[(size_t)k * T + k];
+    const double r = sqrt(lkk * lkk + xk * xk);
+    if (!(r > 0.0) && info == 0) info = k + 1;
+    const double cinv = lkk / r, s = xk / lkk;       // 1/c and s
+    if (lane == 0) L[(size_t)k * T + k] = r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = lane + 64 * q;
+      if (i > k && i < T) {
+        const double lik = (sa * L[(size_t)i * T + k] + s * x[q]) * cinv;
+        x[q] = x[q] / cinv - s * lik;                 // c x_i - s L_ik(new)
+        L[(size_t)i * T + k] = lik;
+      }
+    }
+  }
+  if (lane == 0 && a.info) a.info[m] = info;
+}
+
+// a10 (reference as written, GPI.py:1043): || G^{-1} y ||^2 with G = tril(K) used as if it were a Cholesky factor.
+// One workgroup, column-oriented forward substitution in LDS; T <= 2048.
+__global__ __launch_bounds__(256) void k_trsv_lower_quad(const double* __restrict__ G, int ld, const double* __restrict__ y,
+                                                          int T, double* __restrict__ out) {
+  extern __shared__ double w[];
+  for (int i = threadIdx.x; i < T; i += 256) w[i] = y[i];
+  __syncthreads();
+  for (int k = 0; k < T; ++k) {
+    if (threadIdx.x == 0) w[k] = w[k] / G[(size_t)k * ld + k];
+    __syncthreads();
+    const double wk = w[k];
+    for (int i = k + 1 + threadIdx.x; i < T; i += 256) w[i] = fma(-G[(size_t)i * ld + k], wk, w[i]);
+    __syncthreads();
+  }
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < T; i += 256) s = fma(w[i], w[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
 }
 
 // ------------------------------------------------------------------ per-cluster operators (plan)
@@ -367,6 +523,7 @@ struct PairsArgs {
   int kbeg, kend;        // range of sorted positions sharing one length-scale
   double ell;
   const double* first_noise;
+  const int32_t* sel;    // optional [N]: segment n is scored against cluster sel[n] only; outputs are then [N]
   int K;
   double* out_quad;
   double* out_logdet;
@@ -443,11 +600,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     const int lane = launder(tid) & 63;
     const int g = lane >> 4, c = lane & 15;
     const int kc = a.perm[kk];
+    if (a.sel && a.sel[n] != kc) continue;
     const double* sc = a.scal + 8 * kc;
     const double cc = sc[0], noise = sc[2];
     const bool iso = sc[3] != 0.0;
-    const double fn = a.first_noise ? a.first_noise[(size_t)n * a.K + kc] : 0.0;
-    const size_t oidx = (size_t)n * a.K + kc;
+    const size_t oidx = a.sel ? (size_t)n : (size_t)n * a.K + kc;
+    const double fn = a.first_noise ? a.first_noise[oidx] : 0.0;
     int msk[NB];
 #pragma unroll
     for (int J = 0; J < NB; ++J) msk[J] = __builtin_amdgcn_readfirstlane(amask[J]);
@@ -492,6 +650,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     d4 cov[NB * (NB + 1) / 2];
     // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
     // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
+    const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP + c;
+    double b0[4][NH], b1[4][NH];
+    int k0 = -1, m = msk[0];
+    if (m) {   // first active k-block of the first sweep
+      k0 = __builtin_ctz(m);
+      m &= m - 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int I = 0; I < NH; ++I) b0[s][I] = Mbase[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
+    }
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
       const double* Ej = E + g * TP + 16 * J + c;
@@ -499,25 +668,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
       for (int h = 0; h < 2; ++h) {
         // sweep 1: BJ = M'[16 NH h .. , :] E[:, J] over the ACTIVE k-blocks of column panel J.  M' is symmetric, so
         // row-tile I of the A operand is read as M'[k][16 I + c]: 128 contiguous bytes per 16 lanes, from L2.
-        // Double-buffered at block granularity: 4 k-steps x NH tiles of MFMA cover the next block's 4 NH loads.
-        const double* Mk = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP + 16 * NH * h + c;
+        // Double-buffered at block granularity (4 k-steps x NH tiles of MFMA cover the next block's 4 NH loads);
+        // the first block of the NEXT sweep is requested before this sweep's second half, so it lands under it.
+        const double* Mk = Mbase + 16 * NH * h;
         d4 BJ[NH];
 #pragma unroll
         for (int I = 0; I < NH; ++I) BJ[I] = (d4){0.0, 0.0, 0.0, 0.0};
-        double b0[4][NH], b1[4][NH];
-        int m = msk[J];
-        int k0 = -1, k1 = -1;
-        if (m) {
-          k0 = __builtin_ctz(m);
-          m &= m - 1;
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int I = 0; I < NH; ++I) b0[s][I] = Mk[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
-        }
 #pragma nounroll
         while (k0 >= 0) {
-          k1 = -1;
+          int k1 = -1;
           if (m) {
             k1 = __builtin_ctz(m);
             m &= m - 1;
@@ -547,6 +706,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             const double b = Ej[(16 * k1 + 4 * s) * TP];
 #pragma unroll
             for (int I = 0; I < NH; ++I) BJ[I] = mfma(b1[s][I], b, BJ[I]);
+          }
+        }
+        k0 = -1;
+        if (!(J == NB - 1 && h == 1)) {   // request the first active block of the next sweep now
+          const int Jn = (h == 0) ? J : J + 1, hn = (h == 0) ? 1 : 0;
+          const double* Mn = Mbase + 16 * NH * hn;
+          m = msk[Jn < NB ? Jn : 0];
+          if (m) {
+            k0 = __builtin_ctz(m);
+            m &= m - 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int I = 0; I < NH; ++I) b0[s][I] = Mn[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
           }
         }
         if (h == 0) {
@@ -706,13 +879,14 @@ int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add
 }
 
 int hgp_score_groups_f64(const double* Y, int ldy, const double* mean, long mean_stride, const double* Sigma,
-                         long sigma_stride, int T, const int32_t* item_mat, const double* item_add,
-                         const int32_t* item_off, const int32_t* item_cnt, int n_items, const int32_t* seg_ids,
-                         double jitter_rel, double* out_quad, double* out_logdet, int32_t* out_info, void* stream) {
+                         long sigma_stride, int T, const int32_t* item_mat, const int32_t* item_mean,
+                         const double* item_add, const int32_t* item_off, const int32_t* item_cnt, int n_items,
+                         const int32_t* seg_ids, double jitter_rel, double* out_quad, double* out_logdet,
+                         int32_t* out_info, void* stream) {
   if (!Y || !Sigma || !item_mat || !item_off || !item_cnt || !out_quad || T <= 0 || ldy < T || n_items < 0) return -1;
   if (n_items == 0) return 0;
   if (T > HGP_MAX_T_WAVE) return -2;
-  ScoreArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, item_mat, item_add, item_off, item_cnt, n_items,
+  ScoreArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, item_mat, item_mean, item_add, item_off, item_cnt, n_items,
               seg_ids, jitter_rel, out_quad, out_logdet, out_info};
   dim3 grid((n_items + WAVES - 1) / WAVES), blk(64 * WAVES);
   hipStream_t st = (hipStream_t)stream;
@@ -800,19 +974,21 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
     case 6: hipLaunchKernelGGL(k_wave_potrf<6>, fgrid, blk, 0, st, fa); break;
     default: hipLaunchKernelGGL(k_wave_potrf<8>, fgrid, blk, 0, st, fa); break;
   }
-  const int nt = TP / 16;
-  dim3 ggrid((nt * nt + WAVES - 1) / WAVES, K);
-  hipLaunchKernelGGL(k_gemm16<true>, ggrid, blk, 0, st, p->d_Z, p->d_Z, p->d_Kinv, TP);      // Kinv = Z^T Z
-  hipLaunchKernelGGL(k_gemm16<false>, ggrid, blk, 0, st, p->d_S, p->d_Kinv, p->d_P, TP);     // P = S Kinv
-  hipLaunchKernelGGL(k_gemm16<false>, ggrid, blk, 0, st, p->d_Kinv, p->d_P, p->d_Q, TP);     // Q = Kinv S Kinv
+  const long sm = (long)TP * TP;
+  GemmArgs g1{p->d_Z, p->d_Z, p->d_Kinv, TP, TP, TP, TP, TP, TP, sm, sm, sm, 1.0, 0.0, 1, 0};     // Kinv = Z^T Z
+  GemmArgs g2{p->d_S, p->d_Kinv, p->d_P, TP, TP, TP, TP, TP, TP, sm, sm, sm, 1.0, 0.0, 0, 0};    // P = S Kinv
+  GemmArgs g3{p->d_Kinv, p->d_P, p->d_Q, TP, TP, TP, TP, TP, TP, sm, sm, sm, 1.0, 0.0, 0, 0};    // Q = Kinv S Kinv
+  launch_gemm(g1, K, st);
+  launch_gemm(g2, K, st);
+  launch_gemm(g3, K, st);
   PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap};
   hipLaunchKernelGGL(k_prep_final, dim3(K), dim3(256), 0, st, fin);
   return launch_status();
 }
 
 int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double* y, int N, int Ts,
-                         const double* first_noise, double* out_quad, double* out_logdet, int32_t* out_info,
-                         void* stream) {
+                         const double* first_noise, const int32_t* sel, double* out_quad, double* out_logdet,
+                         int32_t* out_info, void* stream) {
   if (!p || !x || !y || !out_quad || N < 0 || Ts <= 0) return -1;
   if (N == 0) return 0;
   if (Ts > HGP_MAX_T_WAVE) return -2;
@@ -821,7 +997,7 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
   int rc = 0;
   for (size_t gi = 0; gi < p->grp_beg.size() && rc == 0; ++gi) {
     PairsArgs a{x, y, N, Ts, p->d_xb, p->T, p->d_Mp, p->d_ap, p->d_scal, p->d_perm, p->grp_beg[gi], p->grp_end[gi],
-                p->grp_ell[gi], first_noise, p->K, out_quad, out_logdet, out_info};
+                p->grp_ell[gi], first_noise, sel, p->K, out_quad, out_logdet, out_info};
     switch (p->NB) {
       case 2: rc = launch_pairs<2>(a, st); break;
       case 4: rc = launch_pairs<4>(a, st); break;
@@ -830,6 +1006,105 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
     }
   }
   return rc;
+}
+
+int hgp_gemm_batched_f64(int transA, int transB, int M, int N, int Kd, double alpha, const double* A, int lda, long strideA,
+                         const double* B, int ldb, long strideB, double beta, double* C, int ldc, long strideC, int batch,
+                         void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || Kd <= 0 || batch < 0) return -1;
+  if (batch == 0) return 0;
+  GemmArgs g{A, B, C, M, N, Kd, lda, ldb, ldc, strideA, strideB, strideC, alpha, beta, transA, transB};
+  return launch_gemm(g, batch, (hipStream_t)stream);
+}
+
+size_t hgp_matrix_lik_ws_bytes(int T, int b) { return (size_t)b * ((size_t)4 * T * T + T) * sizeof(double) + 256; }
+
+int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* covprev,
+                      int T, int b, double* out, int32_t* info, void* ws, size_t ws_bytes, void* stream) {
+  if (!f_cur || !f_prev || !A || !Gamma || !covprev || !out || !ws || T <= 0 || b < 0) return -1;
+  if (b == 0) return 0;
+  if (T > HGP_MAX_T_WAVE) return -2;
+  if (ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const long tt = (long)T * T;
+  double* Gc = (double*)ws;          // copy of Gamma -> L
+  double* Z = Gc + (size_t)b * tt;   // L^{-1}
+  double* Y = Z + (size_t)b * tt;    // Z A
+  double* Y2 = Y + (size_t)b * tt;   // Y P  (and z = Z r in its first T entries per item afterwards)
+  double* r = Y2 + (size_t)b * tt;   // residuals [b,T]
+  if (hipMemcpyAsync(Gc, Gamma, sizeof(double) * b * tt, hipMemcpyDeviceToDevice, st) != hipSuccess) return launch_status();
+  int rc = hgp_potrf_batched_f64(Gc, T, b, 1e-8, 0.0, Z, nullptr, info, stream);   // _chol_spd(Gamma), GPI_model.py:312
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_lat_resid, dim3(b), dim3(256), 0, st, f_cur, f_prev, A, T, r);
+  GemmArgs g1{Z, A, Y, T, T, T, T, T, T, tt, tt, tt, 1.0, 0.0, 0, 0};
+  if ((rc = launch_gemm(g1, b, st))) return rc;
+  GemmArgs g2{Y, covprev, Y2, T, T, T, T, T, T, tt, tt, tt, 1.0, 0.0, 0, 0};
+  if ((rc = launch_gemm(g2, b, st))) return rc;
+  // trace(A^T Gamma^{-1} A P) = sum (Y P) o Y
+  hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, Y2, Y, tt, tt, tt, -0.5, 0, out);
+  // mahal = || Z r ||^2 : z = Z r as a T x 1 GEMM into Y2
+  GemmArgs g3{Z, r, Y2, T, 1, T, T, 1, 1, tt, (long)T, tt, 1.0, 0.0, 0, 0};
+  if ((rc = launch_gemm(g3, b, st))) return rc;
+  hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, Y2, Y2, tt, tt, (long)T, -0.5, 1, out);
+  return launch_status();
+}
+
+int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov,
+                        const double* scale, long prior_stride, int T, int b, double* out, int32_t* info, void* ws,
+                        size_t ws_bytes, void* stream) {
+  if (!M || !Sigma || !m_mean || !scale || !out || !ws || T <= 0 || b < 0) return -1;
+  if (b == 0) return 0;
+  if (T > HGP_MAX_T_WAVE) return -2;
+  if (ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const long tt = (long)T * T;
+  double* Sc = (double*)ws;
+  double* Z = Sc + (size_t)b * tt;
+  double* D = Z + (size_t)b * tt;
+  double* Y = D + (size_t)b * tt;
+  if (hipMemcpyAsync(Sc, Sigma, sizeof(double) * b * tt, hipMemcpyDeviceToDevice, st) != hipSuccess) return launch_status();
+  int rc = hgp_potrf_batched_f64(Sc, T, b, 0.0, 1e-8, Z, nullptr, info, stream);   // chol(0.5(S+S^T) + 1e-8 I), GPI_model.py:1353
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sub_batched, dim3((unsigned)((tt + 255) / 256), b), dim3(256), 0, st, M, m_mean, tt, prior_stride, tt, D);
+  GemmArgs g1{Z, D, Y, T, T, T, T, T, T, tt, tt, tt, 1.0, 0.0, 0, 0};              // Y = L^{-1} D
+  if ((rc = launch_gemm(g1, b, st))) return rc;
+  if (m_r_cov) {                                                                     // sum (D R) o Sigma^{-1} D = sum (Y R) o Y
+    GemmArgs g2{Y, m_r_cov, D, T, T, T, T, T, T, tt, prior_stride, tt, 1.0, 0.0, 0, 0};
+    if ((rc = launch_gemm(g2, b, st))) return rc;
+    hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, D, Y, tt, tt, tt, -0.5, 0, out);
+  } else {
+    hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, Y, Y, tt, tt, tt, -0.5, 0, out);
+  }
+  GemmArgs g3{Z, scale, Y, T, T, T, T, T, T, tt, prior_stride, tt, 1.0, 0.0, 0, 0};  // trace(Sigma^{-1} S) = sum (Z S) o Z
+  if ((rc = launch_gemm(g3, b, st))) return rc;
+  hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, Y, Z, tt, tt, tt, -0.5, 1, out);
+  return launch_status();
+}
+
+int hgp_warp_cov_f64(const double* x, int T, double rho, double omega, double diag_add, int normalize, double* K_out,
+                     void* stream) {
+  if (!x || !K_out || T <= 0 || !(rho > 0.0)) return -1;
+  const size_t tot = (size_t)T * T;
+  hipLaunchKernelGGL(k_warp_cov, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, T, rho, omega,
+                     diag_add, normalize, K_out);
+  return launch_status();
+}
+
+int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const double* beta, int T, int b, int32_t* info,
+                       void* stream) {
+  if (!L || !v || T <= 0 || b < 0) return -1;
+  if (b == 0) return 0;
+  if (T > 256) return -2;
+  Rank1Args a{L, v, alpha, beta, T, b, info};
+  hipLaunchKernelGGL(k_chol_rank1, dim3((b + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, double* out, void* stream) {
+  if (!G || !y || !out || T <= 0 || ld < T) return -1;
+  if (T > 2048) return -2;
+  hipLaunchKernelGGL(k_trsv_lower_quad, dim3(1), dim3(256), sizeof(double) * T, (hipStream_t)stream, G, ld, y, T, out);
+  return launch_status();
 }
 
 }  // extern "C"

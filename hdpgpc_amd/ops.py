@@ -87,7 +87,7 @@ def build_items(mat_of_group, add_of_group, group_sizes):
 
 
 def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids=None, jitter_rel=1e-8,
-                 want_logdet=False, want_info=True):
+                 want_logdet=False, want_info=True, item_mean=None):
     """a4+a6: quad[n] = (Y[n]-mean[s])^T cov_s^{-1} (Y[n]-mean[s]) for the segments of each work item.
 
     Y [N,T]; mean [S,T] or None; Sigma [S,T,T]; item_* host or device int/float arrays; seg_ids [sum cnt] or None.
@@ -107,12 +107,13 @@ def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids
     im, ia = up(item_mat, torch.int32), (None if item_add is None else up(item_add, torch.float64))
     io, ic = up(item_off, torch.int32), up(item_cnt, torch.int32)
     sid = None if seg_ids is None else up(seg_ids, torch.int32)
+    imean = None if item_mean is None else up(item_mean, torch.int32)
     quad = torch.zeros(N, dtype=torch.float64, device=dev)
     logdet = torch.zeros(N, dtype=torch.float64, device=dev) if want_logdet else None
     info = torch.zeros(N, dtype=torch.int32, device=dev) if want_info else None
-    _ffi.check(_ffi.lib.hgp_score_groups_f64(_ptr(Y), T, _ptr(mean), T, _ptr(Sigma), T * T, T, _ptr(im), _ptr(ia), _ptr(io),
-                                             _ptr(ic), im.numel(), _ptr(sid), jitter_rel, _ptr(quad), _ptr(logdet),
-                                             _ptr(info), _stream()), "score_groups")
+    _ffi.check(_ffi.lib.hgp_score_groups_f64(_ptr(Y), T, _ptr(mean), T, _ptr(Sigma), T * T, T, _ptr(im), _ptr(imean),
+                                             _ptr(ia), _ptr(io), _ptr(ic), im.numel(), _ptr(sid), jitter_rel, _ptr(quad),
+                                             _ptr(logdet), _ptr(info), _stream()), "score_groups")
     return quad, logdet, info
 
 
@@ -155,24 +156,29 @@ class PairsPlan:
         s = self.scalars().cpu().numpy()
         return np.finfo(np.float64).eps * (s[:, 0] * s[:, 6]) ** 2
 
-    def loglik(self, x, y, first_noise=None, want_logdet=True, want_info=True):
-        """x, y [N,Ts] -> (quad [N,K], logdet [N,K] or None, info [N,K] or None)."""
+    def loglik(self, x, y, first_noise=None, want_logdet=True, want_info=True, sel=None):
+        """x, y [N,Ts] -> (quad [N,K], logdet [N,K] or None, info [N,K] or None).
+
+        sel [N] int32 (optional): segment n is scored against cluster sel[n] only; outputs (and first_noise) are [N]."""
         x = _dev64(x, "x")
         y = _dev64(y, "y")
         N, Ts = x.shape
         dev = x.device
+        shape = (N,) if sel is not None else (N, self.K)
+        if sel is not None:
+            sel = torch.as_tensor(sel, device=dev).to(torch.int32).contiguous()
         if first_noise is not None:
-            first_noise = _dev64(first_noise.reshape(N, self.K), "first_noise")
-        quad = torch.empty((N, self.K), dtype=torch.float64, device=dev)
-        logdet = torch.empty((N, self.K), dtype=torch.float64, device=dev) if want_logdet else None
-        info = torch.zeros((N, self.K), dtype=torch.int32, device=dev) if want_info else None
-        _ffi.check(_ffi.lib.hgp_loglik_pairs_f64(self._h, _ptr(x), _ptr(y), N, Ts, _ptr(first_noise), _ptr(quad),
+            first_noise = _dev64(first_noise.reshape(shape), "first_noise")
+        quad = torch.zeros(shape, dtype=torch.float64, device=dev)
+        logdet = torch.zeros(shape, dtype=torch.float64, device=dev) if want_logdet else None
+        info = torch.zeros(shape, dtype=torch.int32, device=dev) if want_info else None
+        _ffi.check(_ffi.lib.hgp_loglik_pairs_f64(self._h, _ptr(x), _ptr(y), N, Ts, _ptr(first_noise), _ptr(sel), _ptr(quad),
                                                  _ptr(logdet), _ptr(info), _stream()), "loglik_pairs")
         return quad, logdet, info
 
-    def score(self, x, y, first_noise=None):
+    def score(self, x, y, first_noise=None, sel=None):
         """The reference's score: -0.5 quad - 0.5 Ts log(2 pi)  (GPI_model.py:285, no log-determinant)."""
-        quad, _, info = self.loglik(x, y, first_noise, want_logdet=False)
+        quad, _, info = self.loglik(x, y, first_noise, want_logdet=False, sel=sel)
         return -0.5 * quad - 0.5 * x.shape[1] * LOG2PI, info
 
     def close(self):
@@ -185,3 +191,80 @@ class PairsPlan:
             self.close()
         except Exception:
             pass
+
+
+def gemm_batched(A, B, transA=False, transB=False, alpha=1.0):
+    """C[b] = alpha op(A[b]) op(B[b]) on v_mfma_f64_16x16x4_f64; A [b,m,k] (or [m,k]), B [b,k,n] (or [k,n])."""
+    A = _dev64(A, "A")
+    B = _dev64(B, "B")
+    a3 = A if A.dim() == 3 else A.unsqueeze(0)
+    b3 = B if B.dim() == 3 else B.unsqueeze(0)
+    batch = max(a3.shape[0], b3.shape[0])
+    M, Kd = (a3.shape[2], a3.shape[1]) if transA else (a3.shape[1], a3.shape[2])
+    N = b3.shape[1] if transB else b3.shape[2]
+    sA = 0 if a3.shape[0] == 1 else a3.shape[1] * a3.shape[2]
+    sB = 0 if b3.shape[0] == 1 else b3.shape[1] * b3.shape[2]
+    C = torch.empty((batch, M, N), dtype=torch.float64, device=A.device)
+    _ffi.check(_ffi.lib.hgp_gemm_batched_f64(int(transA), int(transB), M, N, Kd, alpha, _ptr(a3), a3.shape[2], sA, _ptr(b3),
+                                             b3.shape[2], sB, 0.0, _ptr(C), N, M * N, batch, _stream()), "gemm_batched")
+    return C if (A.dim() == 3 or B.dim() == 3) else C[0]
+
+
+def lat_error(f_cur, f_prev, A, Gamma, covprev):
+    """a8 batched: returns (-0.5 (mahal + trace) [b], info [b]); the caller adds -0.5 T log 2pi."""
+    f_cur, f_prev = _dev64(f_cur, "f_cur"), _dev64(f_prev, "f_prev")
+    A, Gamma, covprev = _dev64(A, "A"), _dev64(Gamma, "Gamma"), _dev64(covprev, "covprev")
+    b, T = f_cur.shape
+    out = torch.empty(b, dtype=torch.float64, device=A.device)
+    info = torch.zeros(b, dtype=torch.int32, device=A.device)
+    nws = _ffi.lib.hgp_matrix_lik_ws_bytes(T, b)
+    ws = torch.empty(nws, dtype=torch.uint8, device=A.device)
+    _ffi.check(_ffi.lib.hgp_lat_error_f64(_ptr(f_cur), _ptr(f_prev), _ptr(A), _ptr(Gamma), _ptr(covprev), T, b, _ptr(out),
+                                          _ptr(info), _ptr(ws), nws, _stream()), "lat_error")
+    return out, info
+
+
+def mniw_loglik(M, Sigma, m_mean, m_r_cov, scale):
+    """a9 batched.  M, Sigma [b,T,T]; prior (m_mean, scale, optional m_r_cov) [T,T] shared or [b,T,T] per item."""
+    M, Sigma = _dev64(M, "M"), _dev64(Sigma, "Sigma")
+    b, T, _ = M.shape
+    m_mean, scale = _dev64(m_mean, "m_mean"), _dev64(scale, "scale")
+    stride = 0 if m_mean.dim() == 2 else T * T
+    if m_r_cov is not None:
+        m_r_cov = _dev64(m_r_cov, "m_r_cov")
+    out = torch.empty(b, dtype=torch.float64, device=M.device)
+    info = torch.zeros(b, dtype=torch.int32, device=M.device)
+    nws = _ffi.lib.hgp_matrix_lik_ws_bytes(T, b)
+    ws = torch.empty(nws, dtype=torch.uint8, device=M.device)
+    _ffi.check(_ffi.lib.hgp_mniw_loglik_f64(_ptr(M), _ptr(Sigma), _ptr(m_mean), _ptr(m_r_cov), _ptr(scale), stride, T, b,
+                                            _ptr(out), _ptr(info), _ptr(ws), nws, _stream()), "mniw_loglik")
+    return out, info
+
+
+def warp_cov(x, rho, omega, diag_add, normalize=True):
+    x = _dev64(x.reshape(-1), "x")
+    K = torch.empty((x.numel(), x.numel()), dtype=torch.float64, device=x.device)
+    _ffi.check(_ffi.lib.hgp_warp_cov_f64(_ptr(x), x.numel(), rho, omega, diag_add, int(bool(normalize)), _ptr(K), _stream()),
+               "warp_cov")
+    return K
+
+
+def chol_rank1(L, v, alpha=None, beta=None):
+    """config 5: chol(alpha L L^T + beta v v^T) by a rank-1 update (O(T^2)), batched; returns (L_new, info)."""
+    L = _dev64(L, "L")
+    L3 = (L if L.dim() == 3 else L.unsqueeze(0)).clone()
+    b, T, _ = L3.shape
+    v = _dev64(v.reshape(b, T), "v")
+    al = None if alpha is None else torch.as_tensor(alpha, dtype=torch.float64, device=L.device).reshape(b).contiguous()
+    be = None if beta is None else torch.as_tensor(beta, dtype=torch.float64, device=L.device).reshape(b).contiguous()
+    info = torch.zeros(b, dtype=torch.int32, device=L.device)
+    _ffi.check(_ffi.lib.hgp_chol_rank1_f64(_ptr(L3), _ptr(v), _ptr(al), _ptr(be), T, b, _ptr(info), _stream()), "chol_rank1")
+    return (L3 if L.dim() == 3 else L3[0]), info
+
+
+def trsv_lower_quad(G, y):
+    """|| tril(G)^{-1} y ||^2 (a10 as written in the reference)."""
+    G, y = _dev64(G, "G"), _dev64(y.reshape(-1), "y")
+    out = torch.empty(1, dtype=torch.float64, device=G.device)
+    _ffi.check(_ffi.lib.hgp_trsv_lower_quad_f64(_ptr(G), G.shape[1], _ptr(y), y.numel(), _ptr(out), _stream()), "trsv_lower_quad")
+    return out[0]

@@ -52,7 +52,7 @@ int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add
  * GPI_model.compute_sq_err_all builds on a shared grid (GPI_model.py:516-533).
  * Work item g (one per group chunk) scores `item_cnt[g]` segments against one state:
  *     S    = Sigma + item_mat[g] * sigma_stride          (T x T, leading dimension T)
- *     m    = mean  + item_mat[g] * mean_stride           (T)           (mean == NULL: zero mean)
+ *     m    = mean  + (item_mean ? item_mean[g] : item_mat[g]) * mean_stride   (T)   (mean == NULL: zero mean)
  *     cov  = 0.5 (S + S^T) + item_add[g] I               ("first" inflation, GPI_model.py:527-529)
  *     cov += jitter_rel * max(mean |diag cov|, eps) I    (a3)
  *   for j < item_cnt[g]:  n = seg_ids ? seg_ids[item_off[g] + j] : item_off[g] + j
@@ -61,9 +61,10 @@ int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add
  *     out_info[n]   = LAPACK info of cov   (may be NULL)
  * The reference's score is -0.5 * out_quad - 0.5 * T * log(2 pi). */
 int hgp_score_groups_f64(const double* Y, int ldy, const double* mean, long mean_stride, const double* Sigma,
-                         long sigma_stride, int T, const int32_t* item_mat, const double* item_add,
-                         const int32_t* item_off, const int32_t* item_cnt, int n_items, const int32_t* seg_ids,
-                         double jitter_rel, double* out_quad, double* out_logdet, int32_t* out_info, void* stream);
+                         long sigma_stride, int T, const int32_t* item_mat, const int32_t* item_mean,
+                         const double* item_add, const int32_t* item_off, const int32_t* item_cnt, int n_items,
+                         const int32_t* seg_ids, double jitter_rel, double* out_quad, double* out_logdet,
+                         int32_t* out_info, void* stream);
 
 /* a2 + a5 - the per-(segment, cluster) general path: IterativeGaussianProcess.pred_dist (GPI.py:457-503)
  * followed by the score of GPI_model.log_sq_error (GPI_model.py:250-286), for an N x K batch.
@@ -93,9 +94,51 @@ const double* hgp_pairs_plan_scalars(const hgp_pairs_plan* plan);
  * `first` branch (GPI_model.py:271-273).  Outputs [N,K]: out_quad = d^T cov^{-1} d, out_logdet (may be NULL),
  * out_info (may be NULL).  cov carries the reference's regularisation: +1e-6 I (GPI.py:501, dense Sigma only),
  * + first_noise, + 1e-8 mean|diag| I (GPI_model.py:83-87). */
+/* sel[N] (may be NULL): segment n is scored against cluster sel[n] only - the per-segment LDS step of
+ * GPI_model.compute_sq_err_all's irregular-grid loop (GPI_model.py:535-545); outputs and first_noise are then [N]. */
 int hgp_loglik_pairs_f64(const hgp_pairs_plan* plan, const double* x, const double* y, int N, int Ts,
-                         const double* first_noise, double* out_quad, double* out_logdet, int32_t* out_info,
+                         const double* first_noise, const int32_t* sel, double* out_quad, double* out_logdet,
+                         int32_t* out_info, void* stream);
+
+/* Auxiliary: C[b] = alpha op(A[b]) op(B[b]) + beta C[b] (row-major, any M x N x Kd) on v_mfma_f64_16x16x4_f64.
+ * Replaces the torch.matmul / torch.linalg.multi_dot calls of the matrix-valued terms below. */
+int hgp_gemm_batched_f64(int transA, int transB, int M, int N, int Kd, double alpha, const double* A, int lda, long strideA,
+                         const double* B, int ldb, long strideB, double beta, double* C, int ldc, long strideC, int batch,
                          void* stream);
+
+/* workspace (bytes) of the two matrix-valued likelihood terms below for b items of size T */
+size_t hgp_matrix_lik_ws_bytes(int T, int b);
+
+/* a8 - GPI_model.log_lat_error (GPI_model.py:288-323), batched over b LDS steps:
+ *   r = f_cur - A f_prev;  L = _chol_spd(Gamma);  out = -0.5 (r^T Gamma^{-1} r + tr(A^T Gamma^{-1} A covprev))
+ * (the caller adds -0.5 T log 2pi).  f_cur, f_prev [b,T]; A, Gamma, covprev [b,T,T]. */
+int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* covprev,
+                      int T, int b, double* out, int32_t* info, void* ws, size_t ws_bytes, void* stream);
+
+/* a9 - matrix_normal_inv_wishart.log_likelihood_MNIW (GPI_model.py:1346-1362), batched:
+ *   L = chol(0.5 (Sigma + Sigma^T) + 1e-8 I);  D = M - m_mean
+ *   out = -0.5 sum (D m_r_cov) o (Sigma^{-1} D) - 0.5 tr(Sigma^{-1} scale)
+ * M, Sigma [b,T,T]; the prior (m_mean, m_r_cov, scale) is read with stride prior_stride (0 = shared by all items);
+ * m_r_cov == NULL means the identity (the only value on the hot path, GPI_model.py:481-484). */
+int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov,
+                        const double* scale, long prior_stride, int T, int b, double* out, int32_t* info, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/* a11 - WarpPriorAMTGP._rbf_cov (amtgp_warping_system.py:160-173): omega^2 exp(-0.5 dx^2/rho^2) + diag_add I on the
+ * grid normalised to [0,1] when normalize != 0.  The batch score is then hgp_score_groups_f64 with jitter_rel = 0. */
+int hgp_warp_cov_f64(const double* x, int T, double rho, double omega, double diag_add, int normalize, double* K_out,
+                     void* stream);
+
+/* BASELINE configs[4] - rank-1 update of a Cholesky factor, batched, T <= 256, in place:
+ *   L <- chol(alpha[b] L L^T + beta[b] v v^T)   (alpha, beta may be NULL = 1).
+ * The MNIW scale recursion new_scale = a scale + b e e^T (GPI_model.py:1332-1336) has exactly this form. */
+int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const double* beta, int T, int b, int32_t* info,
+                       void* stream);
+
+/* a10 helper - || G^{-1} y ||^2 for the lower triangle G of a [T, ld] matrix.  IterativeGaussianProcess.
+ * log_marginal_likelihood as written passes K itself as the "factor" to cho_solve (GPI.py:1043); this reproduces
+ * that call with G = tril(K).  out[1]. */
+int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, double* out, void* stream);
 
 #ifdef __cplusplus
 }

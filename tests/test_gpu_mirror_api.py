@@ -1,0 +1,148 @@
+"""GPU parity of the host-side mirror (hdpgpc_amd.GPI_model / GPI / amtgp_warping_system) against outputs of the
+reference itself (tests/golden/*.npz): same method names, same numbers."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+from oracle import hdpgpc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from hdpgpc_amd import ops
+    from hdpgpc_amd.amtgp_warping_system import WarpPriorAMTGP
+    from hdpgpc_amd.GPI import IterativeGaussianProcess, RBFWhiteKernel
+    from hdpgpc_amd.GPI_model import GPI_model, matrix_normal_inv_wishart
+
+RT = 1e-8
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def model_from(g, prefix="st_"):
+    c, ell, noise = (float(v) for v in g[prefix + "theta"])
+    m = GPI_model(RBFWhiteKernel(c, ell, noise), g[prefix + "x_basis"][:, None], bayesian=True)
+    m.load_state(g[prefix + "f_star"], g[prefix + "Sigma"], g[prefix + "C"], g[prefix + "indexes"],
+                 f_star_sm=g[prefix + "f_star_sm"], cov_f_sm=g[prefix + "cov_f_sm"], A=g[prefix + "A"],
+                 Gamma=g[prefix + "Gamma"], A_def=g[prefix + "A_def"], Gamma_def=g[prefix + "Gamma_def"],
+                 C_def=g[prefix + "C_def"], Sigma_def=g[prefix + "Sigma_def"], n0=float(g[prefix + "n0"]))
+    return m
+
+
+@pytest.mark.parametrize("tag", ["t30", "t45", "t90"])
+def test_gpi_model_scoring_half(tag):
+    g = golden(f"state_{tag}.npz")
+    m = model_from(g)
+    y = g["y"]
+    n, T = y.shape
+    xs = np.repeat(g["st_x_basis"][None, :, None], n, axis=0)
+    yt = y[:, :, None]
+    # a6 shared grid (with and without the `first` inflation) and irregular grids
+    assert rel_err(m.compute_sq_err_all(xs, yt).cpu().numpy(), g["q_shared"]) < RT
+    assert rel_err(m.compute_sq_err_all(xs, yt, no_first=True).cpu().numpy(), g["q_shared_nofirst"]) < RT
+    assert rel_err(m.compute_sq_err_all(g["x_irr"][:, :, None], yt).cpu().numpy(), g["q_irr"]) < RT
+    # a8
+    ql = m.compute_q_lat_all(dev(xs)).cpu().numpy()
+    assert rel_err(ql[m.indexes], g["q_lat"][m.indexes]) < RT
+    assert np.all(np.delete(ql, m.indexes) == 0.0)
+    assert abs(float(m.log_lat_error(1, 1.0)) - g["q_lat"][m.indexes[1]]) <= RT * abs(g["q_lat"][m.indexes[1]])
+    # a5: the online-style calls
+    for j in (0, n - 1):
+        assert abs(float(m.log_sq_error(g["x_irr"][j][:, None], y[j][:, None], i=-1)) - g["lse_last"][j]) <= RT * abs(g["lse_last"][j])
+        assert abs(float(m.log_sq_error(xs[j], y[j][:, None], i=-1)) - g["lse_last_shared"][j]) <= RT * abs(g["lse_last_shared"][j])
+        assert abs(float(m.log_sq_error(g["x_irr"][j][:, None], y[j][:, None])) - g["lse_none"][j]) <= RT * abs(g["lse_none"][j])
+        v = m.log_sq_error(g["x_irr"][j][:, None], y[j][:, None], mean=g["st_f_star_sm"][-2], cov=g["st_cov_f_sm"][-2],
+                           C=g["st_C"][-2], Sigma=g["st_Sigma"][-2], i=0, first=True)
+        assert abs(float(v) - g["lse_params_first"][j]) <= RT * abs(g["lse_params_first"][j])
+    # a9
+    assert abs(float(m.return_LDS_param_likelihood()) - float(g["lds_lik"])) <= RT * abs(float(g["lds_lik"]))
+    assert abs(float(m.return_LDS_param_likelihood(first=True)) - float(g["lds_lik_first"])) <= RT * abs(float(g["lds_lik_first"]))
+    prior = matrix_normal_inv_wishart(dev(g["st_C_def"]), torch.eye(T, dtype=torch.float64, device="cuda"), 5, dev(g["st_Sigma_def"]))
+    v = prior.log_likelihood_MNIW(dev(g["st_C"][-1]), dev(g["st_Sigma"][-1]), float(g["st_n0"]))
+    assert abs(float(v) - float(g["mniw_obs"])) <= RT * abs(float(g["mniw_obs"]))
+    # a7 + a2: observe_last on the dense plotting grid (T* = 2T-1 > T)
+    f, cov = m.observe_last(g["x_dense"][:, None])
+    assert np.allclose(f.cpu().numpy()[:, 0], g["obs_last_f"], rtol=1e-7, atol=1e-7 * np.abs(g["obs_last_f"]).max())
+    assert np.allclose(cov.cpu().numpy(), g["obs_last_cov"], rtol=1e-7, atol=1e-7 * np.abs(g["obs_last_cov"]).max())
+
+
+def test_pred_dist_and_latent_golden():
+    g = golden("pred_dist.npz")
+    for i in range(int(g["n_cases"])):
+        c, ell, noise = (float(v) for v in g[f"c{i}_theta"])
+        gp = IterativeGaussianProcess(RBFWhiteKernel(c, ell, noise), g[f"c{i}_xb"][:, None])
+        f, cov = gp.pred_dist(g[f"c{i}_xp"][:, None], g[f"c{i}_xb"][:, None], g[f"c{i}_mean"][:, None], g[f"c{i}_Sigma"])
+        assert np.allclose(f.cpu().numpy()[:, 0], g[f"c{i}_f"], rtol=1e-7, atol=1e-7 * np.abs(g[f"c{i}_f"]).max())
+        assert np.allclose(cov.cpu().numpy(), g[f"c{i}_cov"], rtol=1e-7, atol=1e-7 * np.abs(g[f"c{i}_cov"]).max())
+        fl, covl = gp.pred_latent_dist(g[f"c{i}_xp"][:, None], g[f"c{i}_xb"][:, None], g[f"c{i}_mean"][:, None], g[f"c{i}_Sigma"])
+        assert np.allclose(fl.cpu().numpy()[:, 0], g[f"c{i}_f_lat"], rtol=1e-6, atol=1e-6 * np.abs(g[f"c{i}_f_lat"]).max())
+        assert np.allclose(covl.cpu().numpy(), g[f"c{i}_cov_lat"], rtol=1e-6, atol=1e-6 * np.abs(g[f"c{i}_cov_lat"]).max())
+
+
+def test_lml_a10_golden():
+    g = golden("lml.npz")
+    for i in range(int(g["n_cases"])):
+        c, ell, noise = (float(v) for v in g[f"c{i}_theta"])
+        gp = IterativeGaussianProcess(RBFWhiteKernel(c, ell, noise), g[f"c{i}_x"][:, None])
+        v = gp.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], None)
+        assert abs(v - float(g[f"c{i}_lml"])) <= 1e-8 * abs(float(g[f"c{i}_lml"]))
+        v2 = gp.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], None, faithful=False)
+        ref2 = orc.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], (c, ell, noise), faithful=False)
+        assert abs(v2 - ref2) <= 1e-8 * abs(ref2)
+
+
+def test_warp_prior_a11_golden():
+    g = golden("warp_prior.npz")
+    for i in range(int(g["n_cases"])):
+        rho, omega, noise2, jitter, norm = (float(v) for v in g[f"c{i}_par"])
+        wp = WarpPriorAMTGP(noise_warp=noise2, bound_noise_warp=(1e-10, 1e10), jitter=jitter, normalize_x=bool(norm))
+        wp.theta = (rho, omega)
+        v = wp.log_sq_error_batch(g[f"c{i}_x"], g[f"c{i}_W"])
+        assert rel_err(v.cpu().numpy(), g[f"c{i}_val"]) < RT
+        assert abs(float(wp.log_sq_error(g[f"c{i}_x"], g[f"c{i}_W"][0])) - float(g[f"c{i}_one"])) <= RT * abs(float(g[f"c{i}_one"]))
+
+
+def test_offline_trace_q_matrix_and_assignments():
+    """The q matrix of a real include_batch run of the reference (record 102, 60 beats, T=45, 5 clusters)."""
+    g = golden("offline_r102_t45.npz")
+    y, xb = g["y"], g["x_basis"]
+    N, M, T = y.shape[0], int(g["M"]), xb.size
+    q = np.zeros((N, M))
+    xs = np.repeat(xb[None, :, None], N, axis=0)
+    for m in range(M):
+        c, ell, noise = (float(v) for v in g[f"m{m}_theta"])
+        mod = GPI_model(RBFWhiteKernel(c, ell, noise), xb[:, None])
+        S = g[f"m{m}_Sigma"].shape[0]
+        mod.load_state(g[f"m{m}_means"], g[f"m{m}_Sigma"], np.repeat(np.eye(T)[None], S, 0), g[f"m{m}_indexes"])
+        q[:, m] = mod.compute_sq_err_all(xs, y[:, :, None]).cpu().numpy()
+    assert rel_err(q, g["q"]) < RT
+    assert np.array_equal(np.argmax(q, axis=1), np.argmax(g["q"], axis=1))        # hard assignments bit-identical
+
+
+def test_chol_rank1_config5():
+    rng = np.random.default_rng(8)
+    for T, b in ((30, 3), (90, 4), (256, 2)):
+        Q = rng.normal(size=(b, T, T))
+        A = Q @ Q.transpose(0, 2, 1) / T + np.eye(T)
+        L = np.linalg.cholesky(A)
+        v = rng.normal(size=(b, T))
+        al, be = rng.uniform(0.5, 1.5, b), rng.uniform(0.1, 2.0, b)
+        Ln, info = ops.chol_rank1(dev(L), dev(v), al, be)
+        assert int(info.abs().max()) == 0
+        for k in range(b):
+            ref = orc.chol_rank1_update(L[k], v[k], al[k], be[k])
+            assert np.allclose(Ln[k].cpu().numpy(), ref, rtol=1e-10, atol=1e-11)
+
+
+def test_gemm_batched_shapes():
+    rng = np.random.default_rng(2)
+    for (m, n, k) in ((5, 7, 3), (16, 16, 16), (90, 1, 90), (33, 178, 90)):
+        A, B = rng.normal(size=(3, m, k)), rng.normal(size=(3, k, n))
+        assert np.allclose(ops.gemm_batched(dev(A), dev(B)).cpu().numpy(), A @ B, rtol=1e-12, atol=1e-12)
+        At = np.ascontiguousarray(A.transpose(0, 2, 1))
+        assert np.allclose(ops.gemm_batched(dev(At), dev(B), transA=True).cpu().numpy(), A @ B, rtol=1e-12, atol=1e-12)
+        Bt = np.ascontiguousarray(B.transpose(0, 2, 1))
+        assert np.allclose(ops.gemm_batched(dev(A), dev(Bt), transB=True).cpu().numpy(), A @ B, rtol=1e-12, atol=1e-12)
