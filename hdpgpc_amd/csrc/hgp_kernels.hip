@@ -128,6 +128,7 @@ struct ScoreArgs {
   const double* Sigma;
   long sigma_stride;
   int T;
+  int ld_sigma;               // leading dimension of every Sigma matrix (= T for the public entry point)
   const int32_t* item_mat;
   const int32_t* item_mean;   // optional: row of `mean` per item (default: item_mat)
   const double* item_add;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_score(ScoreArgs a) {
   d4 U[NB * (NB + 1) / 2];
   d4 R[NB];
   double* Wl = w_all + wave * NB * 256;
-  load_sym_upper<NB>(U, S, T, T, lane);
+  load_sym_upper<NB>(U, S, a.ld_sigma, T, lane);
   const double add = a.item_add ? a.item_add[it] : 0.0;
   if (add != 0.0) add_diag<NB>(U, add, T, lane);
   if (a.jitter_rel != 0.0) {
@@ -198,6 +199,191 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_score(ScoreArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ 128 < T <= 256: cooperative kernels
+// One workgroup (4 waves) per matrix / work item; see Coop<> in tile_f64.hpp.
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_coop_score(ScoreArgs a) {
+  using C = Coop<NB>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* rowbuf = smem;
+  double* Rbuf = rowbuf + NB * 256;
+  double* Wbuf = Rbuf + NB * 256;
+  double* scr = Wbuf + 256;
+  double* red = scr + DIAG_SCR;
+  int* redi = reinterpret_cast<int*>(red + 8);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int it = blockIdx.x;
+  const int T = a.T;
+  const int mat = a.item_mat[it];
+  const double* S = a.Sigma + (size_t)mat * a.sigma_stride;
+  const double* mu = a.mean ? a.mean + (size_t)(a.item_mean ? a.item_mean[it] : mat) * a.mean_stride : nullptr;
+  const double add = a.item_add ? a.item_add[it] : 0.0;
+  const int off = a.item_off[it], cnt = a.item_cnt[it];
+  d4 U[C::NT];
+  for (int base = 0; base < cnt; base += 16) {     // every chunk of 16 segments refactors (rare for T > 128)
+    coop_load_sym_upper<NB>(U, S, a.ld_sigma, T, wave, lane);
+    {
+      double sh = add;
+      if (a.jitter_rel != 0.0) {
+        const double dm = coop_diag_abs_mean<NB>(U, T, wave, lane, add, red);
+        sh += a.jitter_rel * fmax(dm, F64_EPS);
+      }
+      if (sh != 0.0) coop_add_diag<NB>(U, sh, T, wave, lane);
+    }
+    const int j = base + c;
+    const bool live = j < cnt;
+    const int seg = live ? (a.seg_ids ? a.seg_ids[off + j] : off + j) : 0;
+    const double* yr = a.Y + (size_t)seg * a.ldy;
+    for (int K = wave; K < NB; K += WAVES) {
+      d4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * K + g + 4 * r;
+        v[r] = (live && i < T) ? yr[i] - (mu ? mu[i] : 0.0) : 0.0;
+      }
+      lds_tile_store(Rbuf, K, lane, v);
+    }
+    __syncthreads();
+    PivotAcc pa;
+    pa.init();
+    coop_factor<NB, true>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T);
+    int info;
+    const double ld = coop_logdet_info(pa, wave, lane, red, redi, info);
+    // quad_j = sum over all tiles of Z^2 in column j
+    double q = 0.0;
+    for (int K = wave; K < NB; K += WAVES) {
+      const d4 z = lds_tile_load(Rbuf, K, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q = fma(z[r], z[r], q);
+    }
+    q = xrow_sum(q);
+    if (g == 0) Wbuf[wave * 16 + c] = q;
+    __syncthreads();
+    if (wave == 0 && g == 0 && live) {
+      a.out_quad[seg] = Wbuf[c] + Wbuf[16 + c] + Wbuf[32 + c] + Wbuf[48 + c];
+      if (a.out_logdet) a.out_logdet[seg] = ld;
+      if (a.out_info) a.out_info[seg] = info;
+    }
+    __syncthreads();
+  }
+}
+
+// in-place factor: A <- L (zeros above), info, logdet
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_coop_potrf(PotrfArgs a) {
+  using C = Coop<NB>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* rowbuf = smem;
+  double* Rbuf = rowbuf + NB * 256;
+  double* Wbuf = Rbuf + NB * 256;
+  double* scr = Wbuf + 256;
+  double* red = scr + DIAG_SCR;
+  int* redi = reinterpret_cast<int*>(red + 8);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int m = blockIdx.x;
+  const int T = a.T;
+  double* A = a.A + (size_t)m * T * T;
+  d4 U[C::NT];
+  coop_load_sym_upper<NB>(U, A, T, T, wave, lane);
+  {
+    double sh = a.add;
+    if (a.jitter_rel != 0.0) {
+      const double dm = coop_diag_abs_mean<NB>(U, T, wave, lane, a.add, red);
+      sh += a.jitter_rel * fmax(dm, F64_EPS);
+    }
+    if (sh != 0.0) coop_add_diag<NB>(U, sh, T, wave, lane);
+  }
+  __syncthreads();   // every wave has loaded its tiles before anyone overwrites A
+  PivotAcc pa;
+  pa.init();
+  coop_factor<NB, false>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, A, T, T);
+  int info;
+  const double ld = coop_logdet_info(pa, wave, lane, red, redi, info);
+  if (threadIdx.x == 0) {
+    if (a.info) a.info[m] = info;
+    if (a.logdet) a.logdet[m] = ld;
+  }
+  for (int idx = threadIdx.x; idx < T * T; idx += 64 * WAVES) {   // zeros above the diagonal blocks
+    const int i = idx / T, j = idx % T;
+    if ((j >> 4) > (i >> 4)) A[idx] = 0.0;
+  }
+}
+
+// Linv[:, 16 Jc ..] = L^{-1} e for block column Jc = blockIdx.y: factor again with the identity block as right-hand
+// side (reads A, which must still hold the input: launched BEFORE k_coop_potrf on the same stream).
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_coop_inv(PotrfArgs a) {
+  using C = Coop<NB>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* rowbuf = smem;
+  double* Rbuf = rowbuf + NB * 256;
+  double* Wbuf = Rbuf + NB * 256;
+  double* scr = Wbuf + 256;
+  double* red = scr + DIAG_SCR;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int m = blockIdx.x, Jc = blockIdx.y;
+  const int T = a.T;
+  if (16 * Jc >= T) return;
+  const double* A = a.A + (size_t)m * T * T;
+  d4 U[C::NT];
+  coop_load_sym_upper<NB>(U, A, T, T, wave, lane);
+  {
+    double sh = a.add;
+    if (a.jitter_rel != 0.0) {
+      const double dm = coop_diag_abs_mean<NB>(U, T, wave, lane, a.add, red);
+      sh += a.jitter_rel * fmax(dm, F64_EPS);
+    }
+    if (sh != 0.0) coop_add_diag<NB>(U, sh, T, wave, lane);
+  }
+  for (int K = wave; K < NB; K += WAVES) {
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (K == Jc && g + 4 * r == c) ? 1.0 : 0.0;
+    lds_tile_store(Rbuf, K, lane, v);
+  }
+  __syncthreads();
+  PivotAcc pa;
+  pa.init();
+  coop_factor<NB, true>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T);
+  double* Z = a.Linv + (size_t)m * T * T;
+  for (int K = wave; K < NB; K += WAVES) {
+    const d4 z = lds_tile_load(Rbuf, K, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * K + g + 4 * r, j = 16 * Jc + c;
+      if (i < T && j < T) Z[(size_t)i * T + j] = (K >= Jc) ? z[r] : 0.0;
+    }
+  }
+}
+
+template <int NB>
+int launch_coop_score(const ScoreArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coop_score<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_coop_score<NB>, dim3(a.n_items), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
+template <int NB>
+int launch_coop_potrf(const PotrfArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coop_potrf<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coop_inv<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (a.Linv) hipLaunchKernelGGL(k_coop_inv<NB>, dim3(a.b, NB), dim3(64 * WAVES), lds, st, a);
+  hipLaunchKernelGGL(k_coop_potrf<NB>, dim3(a.b), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
 // --------------------------------------------------------------------------- batched tile GEMM
 // C[b] = alpha op(A[b]) op(B[b]) + beta C[b], any M x N x Kd, one wave per 16x16 tile of C, operands straight
 // from global memory (L2).  Used for per-cluster operators and for the matrix-valued likelihood terms (a8, a9),
@@ -210,6 +396,8 @@ struct GemmArgs {
   long sA, sB, sC;
   double alpha, beta;
   int tA, tB;
+  int nb2 = 1;                 // optional second batch level: item b = b1 * nb2 + b2 uses offsets b1 * s?  + b2 * s?2
+  long sA2 = 0, sB2 = 0, sC2 = 0;
 };
 
 __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
@@ -219,9 +407,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   const int tile = blockIdx.x * WAVES + wave;
   if (tile >= ntm * ntn) return;
   const int ti = tile / ntn, tj = tile % ntn;
-  const double* A = a.A + (size_t)blockIdx.y * a.sA;
-  const double* B = a.B + (size_t)blockIdx.y * a.sB;
-  double* C = a.C + (size_t)blockIdx.y * a.sC;
+  const int b1 = blockIdx.y / a.nb2, b2 = blockIdx.y % a.nb2;
+  const double* A = a.A + (size_t)b1 * a.sA + (size_t)b2 * a.sA2;
+  const double* B = a.B + (size_t)b1 * a.sB + (size_t)b2 * a.sB2;
+  double* C = a.C + (size_t)b1 * a.sC + (size_t)b2 * a.sC2;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
   const int row = 16 * ti + c, col = 16 * tj + c;
   for (int kk = 0; kk < (a.Kd + 3) / 4; ++kk) {
@@ -785,6 +974,89 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- a2 + a5 for 128 < T <= 256 (HBM-staged)
+// The register/LDS-resident pairs kernel cannot hold a 256 x 256 pair.  For these sizes the same algebra runs as a
+// pipeline over chunks of segments with the intermediates in HBM: E -> B = M' E -> C = E^T B -> cov -> cooperative
+// factor/solve.  Correct and general; its traffic (about 3 TP^2 doubles written and read per pair) is what the fused
+// kernel avoids, so it is a stop-gap for the large-T configuration, not the design point.
+struct BigArgs {
+  const double* x;
+  const double* y;
+  int n0, nc, Ts, T, TP, K;
+  const double* xb;
+  const double* scal;
+  const double* ap;
+  const int32_t* perm;
+  int kbeg, kend;
+  double ell;
+  const double* first_noise;
+  double* E;      // [nc, TP, TP]
+  double* C;      // [nc, K, TP, TP]  (E^T M' E, then the finished covariance)
+  double* f;      // [nc, K, TP]      (E^T a', then d = y - f)
+  int32_t* item_mat;
+  int32_t* item_off;
+  int32_t* item_cnt;
+  double* item_add;
+};
+
+__global__ __launch_bounds__(256) void k_big_E(BigArgs a) {
+  const int nl = blockIdx.y;
+  const size_t n = (size_t)a.n0 + nl;
+  const int TP = a.TP;
+  double* E = a.E + (size_t)nl * TP * TP;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < TP * TP; idx += gridDim.x * 256) {
+    const int k = idx / TP, j = idx % TP;
+    double v = 0.0;
+    if (k < a.T && j < a.Ts) {
+      const double u = a.xb[k] / a.ell - a.x[n * a.Ts + j] / a.ell;
+      v = exp(-0.5 * (u * u));
+    }
+    E[idx] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_big_finish(BigArgs a) {
+  const int nl = blockIdx.y, kk = a.kbeg + blockIdx.z;
+  const int kc = a.perm[kk];
+  const size_t n = (size_t)a.n0 + nl;
+  const int TP = a.TP, Ts = a.Ts;
+  const double* sc = a.scal + 8 * kc;
+  const double cc = sc[0], noise = sc[2];
+  const bool iso = sc[3] != 0.0;
+  const size_t p = (size_t)nl * a.K + kc;
+  double* C = a.C + p * TP * TP;
+  const double* xr = a.x + n * Ts;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < TP * TP; idx += gridDim.x * 256) {
+    const int i = idx / TP, j = idx % TP;
+    if (j < i) continue;                              // the factor kernels symmetrise on load: fill both halves
+    double v;
+    if (i < Ts && j < Ts) {
+      if (iso) {
+        v = (i == j) ? sc[4] : 0.0;
+      } else {
+        const double u = xr[i] / a.ell - xr[j] / a.ell;
+        const double kss = (i == j) ? cc + noise : cc * exp(-0.5 * (u * u));
+        v = kss + 0.5 * (C[(size_t)i * TP + j] + C[(size_t)j * TP + i]);
+      }
+    } else {
+      v = (i == j) ? 1.0 : 0.0;
+    }
+    C[(size_t)i * TP + j] = v;
+    C[(size_t)j * TP + i] = v;
+  }
+  if (blockIdx.x == 0) {
+    double* f = a.f + p * TP;
+    for (int j = threadIdx.x; j < TP; j += 256) f[j] = (j < Ts) ? a.y[n * Ts + j] - f[j] : 0.0;
+    if (threadIdx.x == 0) {
+      const double fn = a.first_noise ? a.first_noise[n * a.K + kc] : 0.0;
+      a.item_mat[p] = (int32_t)p;
+      a.item_off[p] = (int32_t)p;
+      a.item_cnt[p] = 1;
+      a.item_add[p] = (iso ? 0.0 : 1e-6) + fn;
+    }
+  }
+}
+
 template <int NB>
 int launch_pairs(const PairsArgs& a, hipStream_t st) {
   size_t lds = pairs_lds_bytes<NB>();
@@ -811,10 +1083,21 @@ struct hgp_pairs_plan {
   // device carve-up
   double *d_theta, *d_scal, *d_A, *d_S, *d_Z, *d_Kinv, *d_P, *d_Q, *d_Mp, *d_ap, *d_xb;
   int32_t* d_perm;
+  // 128 < T: HBM-staged pipeline, chunk of `nchunk` segments
+  bool big = false;
+  int nchunk = 0;
+  double *d_E = nullptr, *d_C = nullptr, *d_f = nullptr, *d_iadd = nullptr, *d_q = nullptr, *d_ld = nullptr;
+  int32_t *d_imat = nullptr, *d_ioff = nullptr, *d_icnt = nullptr, *d_iinfo = nullptr;
 };
 
-static size_t plan_bytes(int T, int Ts_max, int K, size_t* offs /*[12]*/) {
-  const size_t TP = 16 * (size_t)nb_for(std::max(T, Ts_max));
+static int tp_for(int n) {   // padded size: wave kernels {32,64,96,128}, cooperative kernels {192,256}
+  if (n <= HGP_MAX_T_WAVE) return 16 * nb_for(n);
+  return n <= 192 ? 192 : 256;
+}
+static const int BIG_CHUNK = 32;
+
+static size_t plan_bytes(int T, int Ts_max, int K, size_t* offs /*[24]*/) {
+  const size_t TP = (size_t)tp_for(std::max(T, Ts_max));
   const size_t mat = (size_t)K * TP * TP * sizeof(double);
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -822,7 +1105,7 @@ static size_t plan_bytes(int T, int Ts_max, int K, size_t* offs /*[12]*/) {
     o += (bytes + 255) & ~(size_t)255;
     return at;
   };
-  size_t tmp[12];
+  size_t tmp[24] = {0};
   tmp[0] = take((size_t)K * 3 * sizeof(double));   // theta
   tmp[1] = take((size_t)K * 8 * sizeof(double));   // scal
   tmp[2] = take(mat);                              // A  (K~ then L)
@@ -835,6 +1118,19 @@ static size_t plan_bytes(int T, int Ts_max, int K, size_t* offs /*[12]*/) {
   tmp[9] = take((size_t)K * TP * sizeof(double));  // ap
   tmp[10] = take((size_t)K * sizeof(int32_t));     // perm
   tmp[11] = take(TP * sizeof(double));             // x_basis copy
+  if (TP > HGP_MAX_T_WAVE) {
+    const size_t np = (size_t)BIG_CHUNK * K;
+    tmp[12] = take((size_t)BIG_CHUNK * TP * TP * sizeof(double));   // E
+    tmp[13] = take(2 * np * TP * TP * sizeof(double));              // C / cov  +  B = M' E scratch
+    tmp[14] = take(np * TP * sizeof(double));                       // f / d
+    tmp[15] = take(np * sizeof(double));                            // item_add
+    tmp[16] = take(np * sizeof(int32_t));                           // item_mat
+    tmp[17] = take(np * sizeof(int32_t));                           // item_off
+    tmp[18] = take(np * sizeof(int32_t));                           // item_cnt
+    tmp[19] = take(np * sizeof(double));                            // quad
+    tmp[20] = take(np * sizeof(double));                            // logdet
+    tmp[21] = take(np * sizeof(int32_t));                           // info
+  }
   if (offs) memcpy(offs, tmp, sizeof(tmp));
   return o;
 }
@@ -865,8 +1161,9 @@ int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add
                           int32_t* info, void* stream) {
   if (!A || T <= 0 || b < 0) return -1;
   if (b == 0) return 0;
-  if (T > HGP_MAX_T_WAVE) return -2;
+  if (T > HGP_MAX_T_COOP) return -2;
   PotrfArgs a{A, T, b, jitter_rel, add_diag, Linv, logdet, info};
+  if (T > HGP_MAX_T_WAVE) return T <= 192 ? launch_coop_potrf<12>(a, (hipStream_t)stream) : launch_coop_potrf<16>(a, (hipStream_t)stream);
   dim3 grid((b + WAVES - 1) / WAVES), blk(64 * WAVES);
   hipStream_t st = (hipStream_t)stream;
   switch (nb_for(T)) {
@@ -885,9 +1182,10 @@ int hgp_score_groups_f64(const double* Y, int ldy, const double* mean, long mean
                          int32_t* out_info, void* stream) {
   if (!Y || !Sigma || !item_mat || !item_off || !item_cnt || !out_quad || T <= 0 || ldy < T || n_items < 0) return -1;
   if (n_items == 0) return 0;
-  if (T > HGP_MAX_T_WAVE) return -2;
-  ScoreArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, item_mat, item_mean, item_add, item_off, item_cnt, n_items,
+  if (T > HGP_MAX_T_COOP) return -2;
+  ScoreArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, T, item_mat, item_mean, item_add, item_off, item_cnt, n_items,
               seg_ids, jitter_rel, out_quad, out_logdet, out_info};
+  if (T > HGP_MAX_T_WAVE) return T <= 192 ? launch_coop_score<12>(a, (hipStream_t)stream) : launch_coop_score<16>(a, (hipStream_t)stream);
   dim3 grid((n_items + WAVES - 1) / WAVES), blk(64 * WAVES);
   hipStream_t st = (hipStream_t)stream;
   switch (nb_for(T)) {
@@ -907,8 +1205,8 @@ size_t hgp_pairs_plan_device_bytes(int T, int Ts_max, int K) {
 int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const double* theta_host, void* dev_buf,
                           size_t dev_bytes) {
   if (!plan || !theta_host || !dev_buf || T <= 0 || Ts_max <= 0 || K <= 0) return -1;
-  if (T > HGP_MAX_T_WAVE || Ts_max > HGP_MAX_T_WAVE) return -2;
-  size_t offs[12];
+  if (T > HGP_MAX_T_COOP || Ts_max > HGP_MAX_T_COOP) return -2;
+  size_t offs[24];
   if (dev_bytes < plan_bytes(T, Ts_max, K, offs)) return -1;
   for (int k = 0; k < K; ++k)
     if (!(theta_host[3 * k] > 0.0) || !(theta_host[3 * k + 1] > 0.0)) return -1;
@@ -916,8 +1214,10 @@ int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const
   if (!p) return -1;
   p->T = T;
   p->K = K;
-  p->NB = nb_for(std::max(T, Ts_max));
-  p->TP = 16 * p->NB;
+  p->TP = tp_for(std::max(T, Ts_max));
+  p->NB = p->TP / 16;
+  p->big = p->TP > HGP_MAX_T_WAVE;
+  p->nchunk = BIG_CHUNK;
   p->theta.assign(theta_host, theta_host + 3 * (size_t)K);
   p->perm.resize(K);
   for (int k = 0; k < K; ++k) p->perm[k] = k;
@@ -945,6 +1245,18 @@ int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const
   p->d_ap = (double*)(base + offs[9]);
   p->d_perm = (int32_t*)(base + offs[10]);
   p->d_xb = (double*)(base + offs[11]);
+  if (p->big) {
+    p->d_E = (double*)(base + offs[12]);
+    p->d_C = (double*)(base + offs[13]);
+    p->d_f = (double*)(base + offs[14]);
+    p->d_iadd = (double*)(base + offs[15]);
+    p->d_imat = (int32_t*)(base + offs[16]);
+    p->d_ioff = (int32_t*)(base + offs[17]);
+    p->d_icnt = (int32_t*)(base + offs[18]);
+    p->d_q = (double*)(base + offs[19]);
+    p->d_ld = (double*)(base + offs[20]);
+    p->d_iinfo = (int32_t*)(base + offs[21]);
+  }
   if (hipMemcpy(p->d_theta, p->theta.data(), sizeof(double) * 3 * K, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(p->d_perm, p->perm.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice) != hipSuccess) {
     delete p;
@@ -972,7 +1284,9 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
     case 2: hipLaunchKernelGGL(k_wave_potrf<2>, fgrid, blk, 0, st, fa); break;
     case 4: hipLaunchKernelGGL(k_wave_potrf<4>, fgrid, blk, 0, st, fa); break;
     case 6: hipLaunchKernelGGL(k_wave_potrf<6>, fgrid, blk, 0, st, fa); break;
-    default: hipLaunchKernelGGL(k_wave_potrf<8>, fgrid, blk, 0, st, fa); break;
+    case 8: hipLaunchKernelGGL(k_wave_potrf<8>, fgrid, blk, 0, st, fa); break;
+    case 12: launch_coop_potrf<12>(fa, st); break;
+    default: launch_coop_potrf<16>(fa, st); break;
   }
   const long sm = (long)TP * TP;
   GemmArgs g1{p->d_Z, p->d_Z, p->d_Kinv, TP, TP, TP, TP, TP, TP, sm, sm, sm, 1.0, 0.0, 1, 0};     // Kinv = Z^T Z
@@ -991,10 +1305,45 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
                          int32_t* out_info, void* stream) {
   if (!p || !x || !y || !out_quad || N < 0 || Ts <= 0) return -1;
   if (N == 0) return 0;
-  if (Ts > HGP_MAX_T_WAVE) return -2;
-  if (nb_for(Ts) > p->NB) return -2;   // plan was created with a smaller Ts_max
+  if (Ts > HGP_MAX_T_COOP) return -2;
+  if (tp_for(Ts) > p->TP) return -2;   // plan was created with a smaller Ts_max
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
+  if (p->big) {
+    if (sel) return -2;                 // per-segment selection is only wired into the fused kernel
+    const int TP = p->TP, K = p->K;
+    const long tt = (long)TP * TP;
+    for (int n0 = 0; n0 < N && rc == 0; n0 += p->nchunk) {
+      const int nc = std::min(p->nchunk, N - n0);
+      for (size_t gi = 0; gi < p->grp_beg.size() && rc == 0; ++gi) {
+        const int kb = p->grp_beg[gi], ke = p->grp_end[gi], kg = ke - kb;
+        BigArgs a{x, y, n0, nc, Ts, p->T, TP, K, p->d_xb, p->d_scal, p->d_ap, p->d_perm, kb, ke, p->grp_ell[gi],
+                  first_noise, p->d_E, p->d_C, p->d_f, p->d_imat, p->d_ioff, p->d_icnt, p->d_iadd};
+        hipLaunchKernelGGL(k_big_E, dim3(16, nc), dim3(256), 0, st, a);
+        // the clusters of a length-scale group are not contiguous in cluster id: one GEMM batch per cluster
+        for (int kk = kb; kk < ke && rc == 0; ++kk) {
+          const int kc = p->perm[kk];
+          double* Ck = p->d_C + (size_t)kc * tt;                                     // pair (nl, kc): stride K tt
+          double* Bk = p->d_C + (size_t)(p->nchunk * K) * tt + (size_t)kc * tt;     // second half of the chunk buffer
+          GemmArgs g1{p->d_Mp + (size_t)kc * tt, p->d_E, Bk, TP, TP, TP, TP, TP, TP, 0, tt, (long)K * tt, 1.0, 0.0, 0, 0};   // B = M' E
+          if ((rc = launch_gemm(g1, nc, st))) break;
+          GemmArgs g2{p->d_E, Bk, Ck, TP, TP, TP, TP, TP, TP, tt, (long)K * tt, (long)K * tt, 1.0, 0.0, 1, 0};               // C = E^T B
+          if ((rc = launch_gemm(g2, nc, st))) break;
+          GemmArgs g3{p->d_E, p->d_ap + (size_t)kc * TP, p->d_f + (size_t)kc * TP, TP, 1, TP, TP, 1, 1, tt, 0, (long)K * TP, 1.0, 0.0, 1, 0};
+          if ((rc = launch_gemm(g3, nc, st))) break;
+        }
+        if (rc) break;
+        hipLaunchKernelGGL(k_big_finish, dim3(8, nc, kg), dim3(256), 0, st, a);
+      }
+      if (rc) break;
+      // every pair of the chunk is one work item of the cooperative score kernel (T = Ts inside TP x TP storage)
+      ScoreArgs sa{p->d_f, TP, nullptr, 0, p->d_C, tt, Ts, TP, p->d_imat, nullptr, p->d_iadd, p->d_ioff, p->d_icnt, nc * K,
+                   nullptr, 1e-8, out_quad + (size_t)n0 * K, out_logdet ? out_logdet + (size_t)n0 * K : nullptr,
+                   out_info ? out_info + (size_t)n0 * K : nullptr};
+      rc = (TP == 192) ? launch_coop_score<12>(sa, st) : launch_coop_score<16>(sa, st);
+    }
+    return rc;
+  }
   for (size_t gi = 0; gi < p->grp_beg.size() && rc == 0; ++gi) {
     PairsArgs a{x, y, N, Ts, p->d_xb, p->T, p->d_Mp, p->d_ap, p->d_scal, p->d_perm, p->grp_beg[gi], p->grp_end[gi],
                 p->grp_ell[gi], first_noise, sel, p->K, out_quad, out_logdet, out_info};

@@ -343,4 +343,207 @@ __device__ __forceinline__ double diag_abs_mean(const d4 (&U)[NB * (NB + 1) / 2]
   return wave_sum(s) / (double)n;
 }
 
+// =============================================================================================
+// 4-wave cooperative version for 128 < T <= 256 (NB <= 16 tiles): the upper tiles are dealt
+// column-cyclically to the 4 waves of a workgroup (tile (I, J) lives in wave J % 4), 40 tiles =
+// 320 VGPR per wave at NB = 16.  Step K: the owner of column K factors the diagonal block and
+// publishes W through LDS; every wave solves the row-K tiles of its own columns and publishes them
+// (rowbuf); every wave updates its own trailing tiles reading U_KI from rowbuf.  Two workgroup
+// barriers per step.  Right-hand sides (one block column of 16) live in LDS (Rbuf) and are updated
+// by the waves round-robin.
+// =============================================================================================
+template <int NB>
+struct Coop {
+  static_assert(NB % 4 == 0 && NB <= 16, "cooperative factor: NB in {4,8,12,16}");
+  static constexpr int NQ = NB / 4;
+  static constexpr int NT = 2 * NQ * (NQ + 1);   // tiles per wave (shape of the wave that owns the most)
+  __host__ __device__ static constexpr int loc(int I, int q) { return 2 * q * (q + 1) + I; }   // tile (I, 4q + wave)
+  static constexpr int LDS_DOUBLES = NB * 256 /*rowbuf*/ + NB * 256 /*Rbuf*/ + 256 /*Wbuf*/ + DIAG_SCR + 16;
+};
+
+__device__ __forceinline__ d4 lds_tile_load(const double* buf, int tile, int lane) {
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = buf[(tile * 4 + r) * 64 + lane];
+  return v;
+}
+__device__ __forceinline__ void lds_tile_store(double* buf, int tile, int lane, const d4& v) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) buf[(tile * 4 + r) * 64 + lane] = v[r];
+}
+
+template <int NB>
+__device__ __forceinline__ void coop_load_sym_upper(d4 (&U)[Coop<NB>::NT], const double* __restrict__ A, int ld, int n,
+                                                    int wave, int lane_in) {
+#pragma unroll
+  for (int q = 0; q < Coop<NB>::NQ; ++q) {
+#pragma unroll
+    for (int I = 0; I < 4 * q + 4; ++I) {
+      const int lane = launder(lane_in);
+      const int g = lane >> 4, c = lane & 15;
+      const int J = 4 * q + wave;
+      d4 v = (d4){0.0, 0.0, 0.0, 0.0};
+      if (I <= J && J < NB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + g + 4 * r, j = 16 * J + c;
+          double x = 0.0;
+          if (i < n && j < n) x = 0.5 * (A[(size_t)i * ld + j] + A[(size_t)j * ld + i]);
+          else if (i == j) x = 1.0;
+          v[r] = x;
+        }
+      }
+      U[Coop<NB>::loc(I, q)] = v;
+    }
+  }
+}
+
+// sum over i < n of |A_ii + shift| / n, from the diagonal tiles spread over the waves (LDS reduction in red[4])
+template <int NB>
+__device__ __forceinline__ double coop_diag_abs_mean(const d4 (&U)[Coop<NB>::NT], int n, int wave, int lane_in, double shift,
+                                                     double* red) {
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < Coop<NB>::NQ; ++q) {
+#pragma unroll
+    for (int I = 4 * q; I < 4 * q + 4; ++I) {
+      const int lane = launder(lane_in);
+      const int g = lane >> 4, c = lane & 15;
+      if (I == 4 * q + wave) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + g + 4 * r;
+          if (g + 4 * r == c && i < n) s += fabs(U[Coop<NB>::loc(I, q)][r] + shift);
+        }
+      }
+    }
+  }
+  s = wave_sum(s);
+  if (lane_in == 0) red[wave] = s;
+  __syncthreads();
+  const double tot = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return tot / (double)n;
+}
+
+template <int NB>
+__device__ __forceinline__ void coop_add_diag(d4 (&U)[Coop<NB>::NT], double shift, int n, int wave, int lane_in) {
+#pragma unroll
+  for (int q = 0; q < Coop<NB>::NQ; ++q) {
+#pragma unroll
+    for (int I = 4 * q; I < 4 * q + 4; ++I) {
+      const int lane = launder(lane_in);
+      const int g = lane >> 4, c = lane & 15;
+      if (I == 4 * q + wave) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + g + 4 * r;
+          if (g + 4 * r == c && i < n) U[Coop<NB>::loc(I, q)][r] += shift;
+        }
+      }
+    }
+  }
+}
+
+// Factor (and eliminate the 16 right-hand sides held as tiles in Rbuf when RHS).  On exit Rbuf holds Z = L^{-1} R.
+// pa accumulates only the pivots of the columns this wave owns; combine with coop_logdet_info.
+template <int NB, bool RHS>
+__device__ __forceinline__ void coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbuf, double* Rbuf, double* Wbuf, double* scr,
+                                            int wave, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n) {
+  using C = Coop<NB>;
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int qK = K / 4, wK = K % 4;
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+    if (wave == wK) {
+      double* Ld = (Lout != nullptr) ? Lout + (size_t)(16 * K) * ldl + 16 * K : nullptr;
+      const d4 Wd = diag16(U[C::loc(K, qK)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Wbuf[s * 64 + lane] = Wd[s];
+      if (RHS) {   // Z_K = W R_K
+        const d4 rk = lds_tile_load(Rbuf, K, lane);
+        d4 z = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) z = mfma(Wd[s], rk[s], z);
+        lds_tile_store(Rbuf, K, lane, z);
+      }
+    }
+    __syncthreads();
+    d4 W;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) W[s] = Wbuf[s * 64 + lane];
+    // panel: U_KJ = W A_KJ for my columns J > K; publish them
+#pragma unroll
+    for (int q = qK; q < C::NQ; ++q) {
+      const int J = 4 * q + wave;
+      if (J > K && J < NB) {
+        const d4 t = U[C::loc(K, q)];
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(W[s], t[s], acc);
+        U[C::loc(K, q)] = acc;
+        lds_tile_store(rowbuf, J, lane, acc);
+        if (Lout != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * J + c, col = 16 * K + g + 4 * r;
+            if (row < n && col < n) Lout[(size_t)row * ldl + col] = acc[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // trailing: A_IJ -= U_KI^T U_KJ for my columns J > K and K < I <= J
+#pragma unroll
+    for (int q = qK; q < C::NQ; ++q) {
+      const int J = 4 * q + wave;
+      if (J > K && J < NB) {
+        const d4 ukj = U[C::loc(K, q)];
+#pragma unroll
+        for (int I = K + 1; I < 4 * q + 4; ++I) {
+          if (I <= J) {
+            const d4 uki = lds_tile_load(rowbuf, I, lane);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) U[C::loc(I, q)] = mfma_sub(uki[s], ukj[s], U[C::loc(I, q)]);
+          }
+        }
+      }
+    }
+    if (RHS) {   // R_I -= U_KI^T Z_K for I > K, rows dealt to the waves round-robin
+      const d4 zk = lds_tile_load(Rbuf, K, lane);
+#pragma unroll
+      for (int I = K + 1; I < NB; ++I) {
+        if ((I & 3) == wave) {
+          const d4 uki = lds_tile_load(rowbuf, I, lane);
+          d4 ri = lds_tile_load(Rbuf, I, lane);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) ri = mfma_sub(uki[s], zk[s], ri);
+          lds_tile_store(Rbuf, I, lane, ri);
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// combine the per-wave pivot accumulators: returns log det in every thread, info = first failing column (or 0)
+__device__ __forceinline__ double coop_logdet_info(const PivotAcc& pa, int wave, int lane, double* red, int* redi, int& info) {
+  if (lane == 0) {
+    red[wave] = pa.logdet();
+    redi[wave] = pa.info;
+  }
+  __syncthreads();
+  const double ld = red[0] + red[1] + red[2] + red[3];
+  int inf = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (redi[w] != 0 && (inf == 0 || redi[w] < inf)) inf = redi[w];
+  info = inf;
+  __syncthreads();
+  return ld;
+}
+
 }  // namespace hgp

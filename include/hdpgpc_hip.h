@@ -29,6 +29,8 @@ extern "C" {
 #define HGP_ABI_VERSION 1
 /* largest T (basis length) and T* (segment length) served by the register-resident wave kernels */
 #define HGP_MAX_T_WAVE 128
+/* largest T served at all: 128 < T <= 256 runs on 4-wave cooperative kernels (one workgroup per matrix) */
+#define HGP_MAX_T_COOP 256
 
 int hgp_abi_version(void);
 

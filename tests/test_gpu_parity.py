@@ -221,3 +221,55 @@ def test_pairs_block_skipping_on_arbitrary_grids():
     _, q_ref, ld_ref = orc.loglik_pairs(x, b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
     assert rel_err(quad.cpu().numpy(), q_ref) < RT_PAIR
     assert rel_err(logdet.cpu().numpy(), ld_ref) < RT_PAIR
+
+
+# ------------------------------------------------------------------ 128 < T <= 256: cooperative kernels + staged pipeline
+@pytest.mark.parametrize("T", [144, 192, 256])
+def test_large_T_potrf_and_score(T):
+    rng = np.random.default_rng(T)
+    b = 3
+    Q = rng.normal(size=(b, T, T))
+    A = Q @ Q.transpose(0, 2, 1) / T + np.diag(rng.uniform(0.5, 2.0, T)) + 1e-3 * rng.normal(size=(b, T, T))
+    L, info, Linv, logdet = ops.potrf_batched(dev(A), 1e-8, 0.25, want_inv=True, want_logdet=True)
+    assert int(info.abs().max()) == 0
+    for k in range(b):
+        S = 0.5 * (A[k] + A[k].T) + 0.25 * np.eye(T)
+        S = S + 1e-8 * np.mean(np.abs(np.diag(S))) * np.eye(T)
+        ref = np.linalg.cholesky(S)
+        Lh = L[k].cpu().numpy()
+        assert np.allclose(Lh, ref, rtol=1e-10, atol=1e-11)
+        assert np.array_equal(np.triu(Lh, 1), np.zeros_like(Lh))
+        assert np.allclose(Linv[k].cpu().numpy() @ ref, np.eye(T), atol=1e-9)
+        assert abs(float(logdet[k]) - 2 * np.log(np.diag(ref)).sum()) < 1e-9 * T
+    mean = rng.normal(size=(b, T))
+    Y = rng.normal(size=(40, T)) * 2
+    grp = rng.integers(0, b, size=40)
+    order = np.argsort(grp, kind="stable")
+    counts = np.bincount(grp, minlength=b)
+    im, ia, io, ic = ops.build_items(list(range(b)), [0.0, 0.3, 0.0], counts.tolist())
+    # large T: at most 16 segments ride along one factorisation
+    quad, logdet2, info2 = ops.score_groups(dev(Y), dev(mean), dev(A), im, ia, io, ic, seg_ids=order.astype(np.int32), want_logdet=True)
+    assert int(info2.abs().max()) == 0
+    for n in range(40):
+        k = grp[n]
+        cov = A[k] + (0.3 if k == 1 else 0.0) * np.eye(T)
+        q_ref, ld_ref = orc.quad_logdet(Y[n] - mean[k], cov)
+        assert abs(float(quad[n]) - q_ref) <= 1e-9 * abs(q_ref)
+        assert abs(float(logdet2[n]) - ld_ref) <= 1e-9 * abs(ld_ref)
+
+
+@pytest.mark.parametrize("T", [160, 256])
+def test_large_T_pairs(T):
+    N, K = 3, 2
+    b = orc.synthetic_batch(N, K, T, seed=900 + T)
+    if T == 160:
+        b["Sigma"][1] = 2.2 * np.eye(T)                   # iso branch through the staged pipeline
+    fn = np.zeros((N, K))
+    fn[0, 0] = 0.04
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    assert int(plan.info.abs().max()) == 0
+    quad, logdet, info = plan.loglik(dev(b["x"]), dev(b["y"]), first_noise=dev(fn))
+    assert int(info.abs().max()) == 0
+    _, q_ref, ld_ref = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"], first_noise=fn)
+    assert rel_err(quad.cpu().numpy(), q_ref) < RT_PAIR
+    assert rel_err(logdet.cpu().numpy(), ld_ref) < RT_PAIR
