@@ -59,18 +59,17 @@ struct PotrfArgs {
   double* Linv;
   double* logdet;
   int32_t* info;
+  int inv_info = 0;   // k_wave_inv also reports info (used when no in-place factor follows)
 };
 
 template <int NB>
 __global__ __launch_bounds__(64 * WAVES) void k_wave_potrf(PotrfArgs a) {
   __shared__ __attribute__((aligned(16))) double scr_all[WAVES * DIAG_SCR];
-  __shared__ __attribute__((aligned(16))) double w_all[WAVES * NB * 256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
   const int m = blockIdx.x * WAVES + wave;
   if (m >= a.b) return;
   double* scr = scr_all + wave * DIAG_SCR;
-  double* Wl = w_all + wave * NB * 256;
   double* A = a.A + (size_t)m * a.T * a.T;
   const int T = a.T;
   d4 U[NB * (NB + 1) / 2];
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_potrf(PotrfArgs a) {
   }
   PivotAcc pa;
   pa.init();
-  wave_factor<NB, 0>(U, R, scr, Wl, nullptr, lane, pa, A, T, T);
+  wave_factor<NB, 0>(U, R, scr, nullptr, nullptr, lane, pa, A, T, T);
   // zero the strictly upper blocks of the in-place result (torch.linalg.cholesky returns zeros there)
 #pragma unroll
   for (int I = 0; I < NB; ++I)
@@ -100,23 +99,51 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_potrf(PotrfArgs a) {
     if (a.info) a.info[m] = pa.info;
     if (a.logdet) a.logdet[m] = pa.logdet();
   }
-  if (a.Linv) {
-    double* Z = a.Linv + (size_t)m * T * T;
-    for (int Jc = 0; Jc < NB; ++Jc) {
-#pragma unroll
-      for (int K = 0; K < NB; ++K)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) R[K][r] = (K == Jc && g + 4 * r == c) ? 1.0 : 0.0;
-      wave_fwd_solve<NB>(U, Wl, R, lane, Jc);
-#pragma unroll
-      for (int K = 0; K < NB; ++K)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int i = 16 * K + g + 4 * r, j = 16 * Jc + c;
-          if (i < T && j < T) Z[(size_t)i * T + j] = (K >= Jc) ? R[K][r] : 0.0;
-        }
-    }
+}
+
+// L^{-1} of the regularised matrix, one wave per (matrix, block column): the identity block column Jc rides along
+// the factorisation as its 16 right-hand sides.  Reads A (never writes it), so it runs BEFORE an in-place k_wave_potrf.
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_wave_inv(PotrfArgs a) {
+  __shared__ __attribute__((aligned(16))) double scr_all[WAVES * DIAG_SCR];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int w = blockIdx.x * WAVES + wave;
+  const int m = w / NB, Jc = w % NB;
+  const int T = a.T;
+  if (m >= a.b || 16 * Jc >= T) return;
+  double* scr = scr_all + wave * DIAG_SCR;
+  const double* A = a.A + (size_t)m * T * T;
+  d4 U[NB * (NB + 1) / 2];
+  d4 R[NB];
+  load_sym_upper<NB>(U, A, T, T, lane);
+  {
+    double sh = a.add;
+    if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(diag_abs_mean<NB>(U, T, lane, a.add), F64_EPS);
+    if (sh != 0.0) add_diag<NB>(U, sh, T, lane);
   }
+#pragma unroll
+  for (int K = 0; K < NB; ++K)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R[K][r] = (K == Jc && g + 4 * r == c) ? 1.0 : 0.0;
+  PivotAcc pa;
+  pa.init();
+  wave_factor<NB, 1>(U, R, scr, nullptr, nullptr, lane, pa, nullptr, 0, T);
+  double* Z = a.Linv + (size_t)m * T * T;
+#pragma unroll
+  for (int K = 0; K < NB; ++K)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * K + g + 4 * r, j = 16 * Jc + c;
+      if (i < T && j < T) Z[(size_t)i * T + j] = (K >= Jc) ? R[K][r] : 0.0;
+    }
+  if (a.inv_info && Jc == 0 && lane == 0 && a.info) a.info[m] = pa.info;   // block column 0 sees every pivot
+}
+
+template <int NB>
+void launch_wave_inv(const PotrfArgs& a, hipStream_t st) {
+  const int waves = a.b * NB;
+  hipLaunchKernelGGL(k_wave_inv<NB>, dim3((waves + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, st, a);
 }
 
 // -------------------------------------------------------------------------------------- a4 + a6
@@ -623,7 +650,7 @@ __global__ __launch_bounds__(256) void k_prep_build(PrepArgs a) {
     __syncthreads();
   }
   const double jit = 1e-4 * fmax(mean_abs, F64_EPS);           // GPI.py:488
-  if (tid == 0) {
+  if (tid == 0 && blockIdx.y == 0) {
     double* sc = a.scal + 8 * k;
     sc[0] = c;
     sc[1] = ell;
@@ -632,11 +659,11 @@ __global__ __launch_bounds__(256) void k_prep_build(PrepArgs a) {
     sc[4] = mS;
     sc[5] = jit;
   }
-  if (k == 0)
+  if (k == 0 && blockIdx.y == 0)
     for (int i = tid; i < TP; i += 256) a.xb_copy[i] = (i < T) ? a.xb[i] : 0.0;
   double* Ak = a.A + (size_t)k * TP * TP;
   double* Sk = a.S + (size_t)k * TP * TP;
-  for (int idx = tid; idx < TP * TP; idx += 256) {
+  for (int idx = blockIdx.y * 256 + tid; idx < TP * TP; idx += gridDim.y * 256) {
     int i = idx / TP, j = idx % TP;
     double av, sv = 0.0;
     if (i < T && j < T) {
@@ -669,12 +696,13 @@ __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
   const double* Q = a.Q + (size_t)k * TP * TP;
   const double* Ki = a.Kinv + (size_t)k * TP * TP;
   double* Mp = a.Mp + (size_t)k * TP * TP;
-  for (int idx = tid; idx < TP * TP; idx += 256) {
+  for (int idx = blockIdx.y * 256 + tid; idx < TP * TP; idx += gridDim.y * 256) {
     int i = idx / TP, j = idx % TP;
     double v = 0.0;
     if (i < T && j < T) v = (c * c) * (0.5 * (Q[(size_t)i * TP + j] + Q[(size_t)j * TP + i]) - 0.5 * (Ki[(size_t)i * TP + j] + Ki[(size_t)j * TP + i]));
     Mp[idx] = v;
   }
+  if (blockIdx.y != 0) return;
   const double* mu = a.mean + (size_t)k * T;
   __shared__ double red[256];
   double rmax = 0.0;
@@ -682,7 +710,7 @@ __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
     double s = 0.0, rs = 0.0;
     if (i < T)
       for (int j = 0; j < T; ++j) {
-        const double kij = Ki[(size_t)i * TP + j];
+        const double kij = Ki[(size_t)j * TP + i];   // K~^{-1} = Z^T Z is symmetric: read column-wise, coalesced
         s = fma(kij, mu[j], s);
         rs += fabs(kij);
       }
@@ -840,15 +868,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
     // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
     const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP + c;
-    double b0[4][NH], b1[4][NH];
+    double b0[4][NH], b1[4][NH];   // A operands (rows of M') of the current / next k-block
+    double e0[4], e1[4];           // B operands (E[k-block, J]) of the current / next k-block
     int k0 = -1, m = msk[0];
     if (m) {   // first active k-block of the first sweep
       k0 = __builtin_ctz(m);
       m &= m - 1;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int I = 0; I < NH; ++I) b0[s][I] = Mbase[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
+        e0[s] = E[(16 * k0 + 4 * s + g) * TP + c];
+      }
     }
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
@@ -870,15 +901,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             k1 = __builtin_ctz(m);
             m &= m - 1;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
               for (int I = 0; I < NH; ++I) b1[s][I] = Mk[(size_t)(16 * k1 + 4 * s) * TP + 16 * I];
+              e1[s] = Ej[(16 * k1 + 4 * s) * TP];
+            }
           }
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const double b = Ej[(16 * k0 + 4 * s) * TP];
 #pragma unroll
-            for (int I = 0; I < NH; ++I) BJ[I] = mfma(b0[s][I], b, BJ[I]);
+            for (int I = 0; I < NH; ++I) BJ[I] = mfma(b0[s][I], e0[s], BJ[I]);
           }
           if (k1 < 0) break;
           k0 = -1;
@@ -886,15 +918,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             k0 = __builtin_ctz(m);
             m &= m - 1;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
               for (int I = 0; I < NH; ++I) b0[s][I] = Mk[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
+              e0[s] = Ej[(16 * k0 + 4 * s) * TP];
+            }
           }
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const double b = Ej[(16 * k1 + 4 * s) * TP];
 #pragma unroll
-            for (int I = 0; I < NH; ++I) BJ[I] = mfma(b1[s][I], b, BJ[I]);
+            for (int I = 0; I < NH; ++I) BJ[I] = mfma(b1[s][I], e1[s], BJ[I]);
           }
         }
         k0 = -1;
@@ -906,9 +939,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             k0 = __builtin_ctz(m);
             m &= m - 1;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
               for (int I = 0; I < NH; ++I) b0[s][I] = Mn[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
+              e0[s] = E[(16 * k0 + 4 * s + g) * TP + 16 * (Jn < NB ? Jn : 0) + c];
+            }
           }
         }
         if (h == 0) {
@@ -1167,10 +1202,10 @@ int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add
   dim3 grid((b + WAVES - 1) / WAVES), blk(64 * WAVES);
   hipStream_t st = (hipStream_t)stream;
   switch (nb_for(T)) {
-    case 2: hipLaunchKernelGGL(k_wave_potrf<2>, grid, blk, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_wave_potrf<4>, grid, blk, 0, st, a); break;
-    case 6: hipLaunchKernelGGL(k_wave_potrf<6>, grid, blk, 0, st, a); break;
-    default: hipLaunchKernelGGL(k_wave_potrf<8>, grid, blk, 0, st, a); break;
+    case 2: if (Linv) launch_wave_inv<2>(a, st); hipLaunchKernelGGL(k_wave_potrf<2>, grid, blk, 0, st, a); break;
+    case 4: if (Linv) launch_wave_inv<4>(a, st); hipLaunchKernelGGL(k_wave_potrf<4>, grid, blk, 0, st, a); break;
+    case 6: if (Linv) launch_wave_inv<6>(a, st); hipLaunchKernelGGL(k_wave_potrf<6>, grid, blk, 0, st, a); break;
+    default: if (Linv) launch_wave_inv<8>(a, st); hipLaunchKernelGGL(k_wave_potrf<8>, grid, blk, 0, st, a); break;
   }
   return launch_status();
 }
@@ -1276,15 +1311,15 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   hipStream_t st = (hipStream_t)stream;
   const int K = p->K, T = p->T, TP = p->TP;
   PrepArgs pa{x_basis, mean, Sigma, T, TP, K, p->d_theta, p->d_scal, p->d_A, p->d_S, p->d_xb};
-  hipLaunchKernelGGL(k_prep_build, dim3(K), dim3(256), 0, st, pa);
-  // L = chol(K~) in place, Z = L^{-1}
+  hipLaunchKernelGGL(k_prep_build, dim3(K, 8), dim3(256), 0, st, pa);
+  // Z = chol(K~)^{-1}  (the factor itself is not needed)
   PotrfArgs fa{p->d_A, TP, K, 0.0, 0.0, p->d_Z, nullptr, info};
-  dim3 fgrid((K + WAVES - 1) / WAVES), blk(64 * WAVES);
+  fa.inv_info = 1;
   switch (p->NB) {
-    case 2: hipLaunchKernelGGL(k_wave_potrf<2>, fgrid, blk, 0, st, fa); break;
-    case 4: hipLaunchKernelGGL(k_wave_potrf<4>, fgrid, blk, 0, st, fa); break;
-    case 6: hipLaunchKernelGGL(k_wave_potrf<6>, fgrid, blk, 0, st, fa); break;
-    case 8: hipLaunchKernelGGL(k_wave_potrf<8>, fgrid, blk, 0, st, fa); break;
+    case 2: launch_wave_inv<2>(fa, st); break;
+    case 4: launch_wave_inv<4>(fa, st); break;
+    case 6: launch_wave_inv<6>(fa, st); break;
+    case 8: launch_wave_inv<8>(fa, st); break;
     case 12: launch_coop_potrf<12>(fa, st); break;
     default: launch_coop_potrf<16>(fa, st); break;
   }
@@ -1296,7 +1331,7 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   launch_gemm(g2, K, st);
   launch_gemm(g3, K, st);
   PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap};
-  hipLaunchKernelGGL(k_prep_final, dim3(K), dim3(256), 0, st, fin);
+  hipLaunchKernelGGL(k_prep_final, dim3(K, 8), dim3(256), 0, st, fin);
   return launch_status();
 }
 
