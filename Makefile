@@ -11,5 +11,9 @@ $(LIB): $(SRC) $(HDR)
 	mkdir -p hdpgpc_amd/lib
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -mllvm -pragma-unroll-threshold=1048576 -shared -fPIC -Wno-unused-result -o $@ $(SRC)
 
+# diagnostic build with in-kernel cycle stamps (tools/stamps.py); never used by the product path
+stamps: $(SRC) $(HDR)
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -mllvm -pragma-unroll-threshold=1048576 -DHGP_STAMPS -shared -fPIC -Wno-unused-result -o hdpgpc_amd/lib/libhdpgpc_hip_stamps.so $(SRC)
+
 clean:
 	rm -f $(LIB)

@@ -5,8 +5,11 @@ The product path has no CPU fallback: importing this module without the built li
 import ctypes
 import os
 
+import torch  # noqa: F401  (first: the library must bind to the HIP runtime PyTorch-ROCm already loaded, not a second copy)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhdpgpc_hip.so")
+# HGP_LIB selects another build of the same library (only the diagnostic `make stamps` build uses it)
+LIB_PATH = os.environ.get("HGP_LIB") or os.path.join(_HERE, "lib", "libhdpgpc_hip.so")
 
 c_dp = ctypes.c_void_p  # device pointers travel as integers
 

@@ -741,6 +741,9 @@ struct PairsArgs {
   double ell;
   const double* first_noise;
   const int32_t* sel;    // optional [N]: segment n is scored against cluster sel[n] only; outputs are then [N]
+#ifdef HGP_STAMPS
+  unsigned long long* stamps;
+#endif
   int K;
   double* out_quad;
   double* out_logdet;
@@ -753,6 +756,9 @@ struct PairsArgs {
 // the blocks |Kt - J| <= 1 survive, which removes ~60 % of the MFMA work at T = 128.  The decision is taken from the
 // data (any grid), never from an assumed band structure.
 constexpr double PAIRS_CUT = 82.9;
+#ifdef HGP_STAMPS
+static unsigned long long* g_stamp_dev = nullptr;   // host-side handle of the diagnostic counters (8 x u64)
+#endif
 
 template <int NB>
 constexpr size_t pairs_lds_bytes() {
@@ -788,6 +794,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
     xbs[i] = (i < T) ? a.xb[i] / a.ell : -1e150 * (double)(1 + i);
   }
+  int* kmask = amask + 8;   // bit I of kmask[J]: tile (I, J) of K** has an entry above the cut-off (I <= J)
   if (tid < 16) amask[tid] = 0;
   __syncthreads();
   {
@@ -810,25 +817,46 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
         if (lane == 0) atomicOr(&amask[Jb], 1 << Kt);
       }
     }
+    for (int t = wave; t < NB * NB; t += WAVES) {   // same test for the tiles of K** (upper ones)
+      const int I = t / NB, J = t % NB;
+      if (I > J) continue;
+      bool near = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double u = xs[16 * I + g + 4 * r] - xs[16 * J + c];
+        near = near || (0.5 * (u * u) < PAIRS_CUT);
+      }
+      if (__any(near) && lane == 0) atomicOr(&kmask[J], 1 << I);
+    }
   }
   __syncthreads();
 
+  HGP_STAMP_DECL
   for (int kk = a.kbeg + wave; kk < a.kend; kk += WAVES) {
     const int lane = launder(tid) & 63;
     const int g = lane >> 4, c = lane & 15;
     const int kc = a.perm[kk];
     if (a.sel && a.sel[n] != kc) continue;
+    HGP_T0();
     const double* sc = a.scal + 8 * kc;
     const double cc = sc[0], noise = sc[2];
     const bool iso = sc[3] != 0.0;
     const size_t oidx = a.sel ? (size_t)n : (size_t)n * a.K + kc;
     const double fn = a.first_noise ? a.first_noise[oidx] : 0.0;
-    int msk[NB];
+    int msk[NB], kmsk[NB];
 #pragma unroll
-    for (int J = 0; J < NB; ++J) msk[J] = __builtin_amdgcn_readfirstlane(amask[J]);
+    for (int J = 0; J < NB; ++J) {
+      msk[J] = __builtin_amdgcn_readfirstlane(amask[J]);
+      kmsk[J] = __builtin_amdgcn_readfirstlane(kmask[J]);
+    }
 
     // d = y - E^T a'   (a' = c K~^{-1} mean), column block by column block over the active blocks of E
     const double* apk = a.ap + (size_t)kc * TP;
+    double apr[NB][4];   // a'[16 Kt + g + 4 r]: one batch of L2 loads per pair instead of one per block
+#pragma unroll
+    for (int Kt = 0; Kt < NB; ++Kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) apr[Kt][r] = apk[16 * Kt + g + 4 * r];
     double dsq = 0.0;
 #pragma unroll
     for (int Jb = 0; Jb < NB; ++Jb) {
@@ -837,7 +865,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
       for (int Kt = 0; Kt < NB; ++Kt) {
         if (msk[Jb] & (1 << Kt)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p = fma(E[(16 * Kt + g + 4 * r) * TP + 16 * Jb + c], apk[16 * Kt + g + 4 * r], p);
+          for (int r = 0; r < 4; ++r) p = fma(E[(16 * Kt + g + 4 * r) * TP + 16 * Jb + c], apr[Kt][r], p);
         }
       }
       p = xrow_sum(p);
@@ -849,6 +877,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
       }
     }
     __builtin_amdgcn_wave_barrier();
+    HGP_ACC(0);
 
     if (iso) {   // GPI.py:497-498: cov_f = mean(diag Sigma) I
       double v = sc[4] + fn;
@@ -868,102 +897,101 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
     // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
     const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP + c;
-    double b0[4][NH], b1[4][NH];   // A operands (rows of M') of the current / next k-block
-    double e0[4], e1[4];           // B operands (E[k-block, J]) of the current / next k-block
-    int k0 = -1, m = msk[0];
-    if (m) {   // first active k-block of the first sweep
-      k0 = __builtin_ctz(m);
+    // Sweep-1 operand ring: 4 slots of half a k-block each (2 k-steps: 2 x NH rows of M' from L2 + 2 values of E
+    // from LDS).  A slot is refilled right after its MFMAs are issued, i.e. three half-blocks (about 1.5k cycles
+    // of MFMA) before it is used again; the first two blocks of the NEXT sweep are requested at the end of a sweep.
+    double ra[4][2][NH], re[4][2];
+    int kA = -1, kB = -1, m = msk[0];
+#define HGP_FILL(slot, half, blk, Mptr, Jcol)                                                               \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                        \
+    _Pragma("unroll") for (int I_ = 0; I_ < NH; ++I_)                                                       \
+      ra[slot][s_][I_] = (Mptr)[(size_t)(16 * (blk) + 4 * (2 * (half) + s_)) * TP + 16 * I_];               \
+    re[slot][s_] = E[(16 * (blk) + 4 * (2 * (half) + s_) + g) * TP + 16 * (Jcol) + c];                      \
+  }
+#define HGP_MMA(slot)                                                                                       \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                        \
+    _Pragma("unroll") for (int I_ = 0; I_ < NH; ++I_) BJ[I_] = mfma(ra[slot][s_][I_], re[slot][s_], BJ[I_]); \
+  }
+    if (m) {
+      kA = __builtin_ctz(m);
       m &= m - 1;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int I = 0; I < NH; ++I) b0[s][I] = Mbase[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
-        e0[s] = E[(16 * k0 + 4 * s + g) * TP + c];
-      }
+      HGP_FILL(0, 0, kA, Mbase, 0)
+      HGP_FILL(1, 1, kA, Mbase, 0)
+    }
+    if (m) {
+      kB = __builtin_ctz(m);
+      m &= m - 1;
+      HGP_FILL(2, 0, kB, Mbase, 0)
+      HGP_FILL(3, 1, kB, Mbase, 0)
     }
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
-      const double* Ej = E + g * TP + 16 * J + c;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         // sweep 1: BJ = M'[16 NH h .. , :] E[:, J] over the ACTIVE k-blocks of column panel J.  M' is symmetric, so
         // row-tile I of the A operand is read as M'[k][16 I + c]: 128 contiguous bytes per 16 lanes, from L2.
-        // Double-buffered at block granularity (4 k-steps x NH tiles of MFMA cover the next block's 4 NH loads);
-        // the first block of the NEXT sweep is requested before this sweep's second half, so it lands under it.
         const double* Mk = Mbase + 16 * NH * h;
         d4 BJ[NH];
 #pragma unroll
         for (int I = 0; I < NH; ++I) BJ[I] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma nounroll
-        while (k0 >= 0) {
-          int k1 = -1;
+        while (kA >= 0) {
+          int kC = -1, kD = -1;
           if (m) {
-            k1 = __builtin_ctz(m);
+            kC = __builtin_ctz(m);
             m &= m - 1;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-              for (int I = 0; I < NH; ++I) b1[s][I] = Mk[(size_t)(16 * k1 + 4 * s) * TP + 16 * I];
-              e1[s] = Ej[(16 * k1 + 4 * s) * TP];
-            }
           }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int I = 0; I < NH; ++I) BJ[I] = mfma(b0[s][I], e0[s], BJ[I]);
+          HGP_MMA(0)
+          if (kC >= 0) { HGP_FILL(0, 0, kC, Mk, J) }
+          HGP_MMA(1)
+          if (kC >= 0) { HGP_FILL(1, 1, kC, Mk, J) }
+          if (kB < 0) {
+            kA = kC;
+            break;
           }
-          if (k1 < 0) break;
-          k0 = -1;
           if (m) {
-            k0 = __builtin_ctz(m);
+            kD = __builtin_ctz(m);
             m &= m - 1;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-              for (int I = 0; I < NH; ++I) b0[s][I] = Mk[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
-              e0[s] = Ej[(16 * k0 + 4 * s) * TP];
-            }
           }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int I = 0; I < NH; ++I) BJ[I] = mfma(b1[s][I], e1[s], BJ[I]);
-          }
+          HGP_MMA(2)
+          if (kD >= 0) { HGP_FILL(2, 0, kD, Mk, J) }
+          HGP_MMA(3)
+          if (kD >= 0) { HGP_FILL(3, 1, kD, Mk, J) }
+          kA = kC;
+          kB = kD;
         }
-        k0 = -1;
-        if (!(J == NB - 1 && h == 1)) {   // request the first active block of the next sweep now
+        kA = -1;
+        kB = -1;
+        if (!(J == NB - 1 && h == 1)) {   // request the first two active blocks of the next sweep now
           const int Jn = (h == 0) ? J : J + 1, hn = (h == 0) ? 1 : 0;
+          const int Jc = Jn < NB ? Jn : 0;
           const double* Mn = Mbase + 16 * NH * hn;
-          m = msk[Jn < NB ? Jn : 0];
+          m = msk[Jc];
           if (m) {
-            k0 = __builtin_ctz(m);
+            kA = __builtin_ctz(m);
             m &= m - 1;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-              for (int I = 0; I < NH; ++I) b0[s][I] = Mn[(size_t)(16 * k0 + 4 * s) * TP + 16 * I];
-              e0[s] = E[(16 * k0 + 4 * s + g) * TP + 16 * (Jn < NB ? Jn : 0) + c];
-            }
+            HGP_FILL(0, 0, kA, Mn, Jc)
+            HGP_FILL(1, 1, kA, Mn, Jc)
+          }
+          if (m) {
+            kB = __builtin_ctz(m);
+            m &= m - 1;
+            HGP_FILL(2, 0, kB, Mn, Jc)
+            HGP_FILL(3, 1, kB, Mn, Jc)
           }
         }
+        HGP_ACC(1);
         if (h == 0) {
 #pragma unroll
           for (int I = 0; I <= J; ++I) {
             const int ln = launder(lane);
-            d4 kt;
-            double hh[4];
-            bool near = false;
+            d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
+            if (kmsk[J] & (1 << I)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
-              hh[r] = 0.5 * (u * u);
-              near = near || (hh[r] < PAIRS_CUT);
-            }
-            if (__any(near)) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) kt[r] = cc * exp(-hh[r]);
-            } else {
-              kt = (d4){0.0, 0.0, 0.0, 0.0};
+              for (int r = 0; r < 4; ++r) {
+                const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
+                kt[r] = cc * exp(-0.5 * (u * u));
+              }
             }
             if (I == J) {   // exact diagonal of the one-argument kernel call; identity on the padding
 #pragma unroll
@@ -973,21 +1001,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             cov[tix(I, J, NB)] = kt;
           }
         }
+        HGP_ACC(2);
         // sweep 2: cov[I][J] += E[rows h, I]^T BJ over the active blocks (Kt, I) of E; the B operand is the
         // accumulator of sweep 1, untouched.
 #pragma unroll
         for (int Kt = 0; Kt < NH; ++Kt) {
 #pragma unroll
           for (int I = 0; I <= J; ++I) {
+            // operands are read unconditionally (an inactive block holds stale LDS bytes that are never multiplied):
+            // the reads can then be issued ahead of the branch and overlap the previous block's MFMAs
+            double af[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) af[r] = E[(16 * (NH * h + Kt) + 4 * r + g) * TP + 16 * I + c];
             if (msk[I] & (1 << (NH * h + Kt))) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const double* Er = E + (16 * (NH * h + Kt) + 4 * r + g) * TP + c;
-                cov[tix(I, J, NB)] = mfma(Er[16 * I], BJ[Kt][r], cov[tix(I, J, NB)]);
-              }
+              for (int r = 0; r < 4; ++r) cov[tix(I, J, NB)] = mfma(af[r], BJ[Kt][r], cov[tix(I, J, NB)]);
             }
           }
         }
+        HGP_ACC(3);
       }
     }
 
@@ -1000,13 +1032,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     PivotAcc pa;
     pa.init();
     d4 Rnone[NB];
+    HGP_ACC(4);
     const double q = wave_factor<NB, 2>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
     if (lane == 0) {
       a.out_quad[oidx] = q;
       if (a.out_logdet) a.out_logdet[oidx] = pa.logdet();
       if (a.out_info) a.out_info[oidx] = pa.info;
     }
+    HGP_ACC(5);
+#ifdef HGP_STAMPS
+    hgp_acc_[7] += pa.diag_cycles;
+#endif
   }
+#ifdef HGP_STAMPS
+  if ((tid & 63) == 0 && a.stamps)
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
+#endif
 }
 
 // ---------------------------------------------------------------- a2 + a5 for 128 < T <= 256 (HBM-staged)
@@ -1381,7 +1422,11 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
   }
   for (size_t gi = 0; gi < p->grp_beg.size() && rc == 0; ++gi) {
     PairsArgs a{x, y, N, Ts, p->d_xb, p->T, p->d_Mp, p->d_ap, p->d_scal, p->d_perm, p->grp_beg[gi], p->grp_end[gi],
-                p->grp_ell[gi], first_noise, sel, p->K, out_quad, out_logdet, out_info};
+                p->grp_ell[gi], first_noise, sel,
+#ifdef HGP_STAMPS
+                g_stamp_dev,
+#endif
+                p->K, out_quad, out_logdet, out_info};
     switch (p->NB) {
       case 2: rc = launch_pairs<2>(a, st); break;
       case 4: rc = launch_pairs<4>(a, st); break;
@@ -1490,5 +1535,18 @@ int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, dou
   hipLaunchKernelGGL(k_trsv_lower_quad, dim3(1), dim3(256), sizeof(double) * T, (hipStream_t)stream, G, ld, y, T, out);
   return launch_status();
 }
+
+#ifdef HGP_STAMPS
+// diagnostic build: read and reset the phase cycle sums (d/f*, sweep 1, K** init, sweep 2, regularise, factor, -, diag16)
+int hgp_debug_stamps(unsigned long long* out8_host) {
+  if (!g_stamp_dev) {
+    if (hipMalloc(&g_stamp_dev, 64) != hipSuccess) return 1;
+    (void)hipMemset(g_stamp_dev, 0, 64);
+  }
+  if (hipMemcpy(out8_host, g_stamp_dev, 64, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  (void)hipMemset(g_stamp_dev, 0, 64);
+  return 0;
+}
+#endif
 
 }  // extern "C"

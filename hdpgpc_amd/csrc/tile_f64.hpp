@@ -16,6 +16,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Diagnostic build only (make stamps): per-phase cycle sums with s_memtime; no stamp executes in the product build.
+#ifdef HGP_STAMPS
+#define HGP_STAMP_DECL unsigned long long hgp_t_, hgp_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define HGP_T0() hgp_t_ = __builtin_readcyclecounter()
+#define HGP_ACC(i) do { unsigned long long n_ = __builtin_readcyclecounter(); hgp_acc_[i] += n_ - hgp_t_; hgp_t_ = n_; } while (0)
+#else
+#define HGP_STAMP_DECL
+#define HGP_T0()
+#define HGP_ACC(i)
+#endif
+
 namespace hgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -34,13 +45,6 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
 // so the trailing updates need no VALU negation of the panel tiles.
 __device__ __forceinline__ d4 mfma_sub(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
-}
-
-// value of lane `src` (compile-time constant after unrolling) broadcast to the whole wave through SGPRs
-__device__ __forceinline__ double lane_bcast(double v, int src) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
 }
 
 // Opaque copy of a per-lane value.  Everything below is fully unrolled over tiles; without this the
@@ -89,7 +93,12 @@ struct PivotAcc {
   double mant;
   int ex;
   int info;  // 0 = ok, j > 0 = pivot j (1-based) was not positive
+#ifdef HGP_STAMPS
+  unsigned long long diag_cycles;
+  __device__ __forceinline__ void init() { mant = 1.0; ex = 0; info = 0; diag_cycles = 0; }
+#else
   __device__ __forceinline__ void init() { mant = 1.0; ex = 0; info = 0; }
+#endif
   __device__ __forceinline__ void renorm() {
     ex += __builtin_amdgcn_frexp_exp(mant);
     mant = __builtin_amdgcn_frexp_mant(mant);
@@ -98,18 +107,31 @@ struct PivotAcc {
   __device__ __forceinline__ double logdet() const { return log(mant) + (double)ex * 0.6931471805599453; }
 };
 
+// value of lane `src` (compile-time constant after unrolling) broadcast to the whole wave through SGPRs
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // diag16: Cholesky of one 16x16 diagonal block AND the inverse of its factor, by one wave.
 //   in : X  (acc layout; only the upper triangle i <= j is read)
 //   out: returns W = L^{-1} (L = U^T lower) in A-operand layout, w[s] = W[c][4s+g];
 //        if Lout != nullptr lane j < 16 writes row j of L (zeros above the diagonal).
-// Lanes 0..15 hold column j of U (Crout, row by row); lanes 16..31 run the forward substitution
-// L Z = I on column j of Z with the SAME instruction stream: both need the scalars U[m][k]
-// (= L[k][m]), which are broadcast from lane k with v_readlane.
+// Lanes 0..15 hold column j of U; lanes 16..31 run the forward substitution L Z = I on column j of Z with the SAME
+// instruction stream: both need the scalars U[k][k'] (= L[k'][k]), broadcast from lane k' with v_readlane.
+// Right-looking, row by row: once row k is final every later row takes  v[k'] -= U[k][k'] v[k]  independently.
+// Measured alternatives (tools/stamps.py, gfx950): this form 7.6k cycles per block; a v_mov_b64_dpp row_newbcast
+// variant with U and Z in the same lanes 6.4k but +32 VGPR, which spills the NB = 8 kernels (net loss, reverted);
+// v_readlane itself costs ~25 cycles (tools/probe_coexec.hip).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
                                      double* Lout, int ldl, int nvalid) {
   const int g = lane >> 4, c = lane & 15;
+#ifdef HGP_STAMPS
+  const unsigned long long td0 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
   for (int r = 0; r < 4; ++r) scr[(g + 4 * r) * DIAG_LD + c] = X[r];
   __builtin_amdgcn_wave_barrier();
@@ -123,18 +145,16 @@ __device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAc
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    double acc = v[k];
-#pragma unroll
-    for (int m = 0; m < k; ++m) {
-      double s = lane_bcast(v[m], k);                      // U[m][k]
-      acc = fma(-s, v[m], acc);
-    }
-    double piv = lane_bcast(acc, k);                       // u_kk^2
-    if (!(piv > 0.0) && pa.info == 0) pa.info = col0 + k + 1;   // NaN compares false; a bad pivot then poisons
-    pa.mant *= piv;                                             // the outputs with NaN, info says where
+    const double piv = lane_bcast(v[k], k);                    // u_kk^2, fully updated
+    if (!(piv > 0.0) && pa.info == 0) pa.info = col0 + k + 1;  // NaN compares false; a bad pivot then poisons
+    pa.mant *= piv;                                            // the outputs with NaN, info says where
     if ((k & 3) == 3) pa.renorm();       // four pivots between renormalisations: no over/underflow for |log2 piv| < 250
-    v[k] = acc * rsqrt_nr(piv);
-    __builtin_amdgcn_sched_barrier(0);   // keep step k's broadcasts next to their FMAs
+    v[k] *= rsqrt_nr(piv);
+#pragma unroll
+    for (int kp = k + 1; kp < 16; ++kp) {
+      const double s = lane_bcast(v[k], kp);                   // U[k][k'] (= L[k'][k])
+      v[kp] = fma(-s, v[k], v[kp]);
+    }
   }
   if (Lout != nullptr && lane < 16 && lane < nvalid) {
 #pragma unroll
@@ -150,6 +170,10 @@ __device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAc
 #pragma unroll
   for (int s = 0; s < 4; ++s) w[s] = scr[c * DIAG_LD + 4 * s + g];                // W[c][4s+g]
   __builtin_amdgcn_wave_barrier();
+#ifdef HGP_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  pa.diag_cycles += __builtin_readcyclecounter() - td0;
+#endif
   return w;
 }
 
@@ -232,7 +256,9 @@ __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R
       }
       __builtin_amdgcn_wave_barrier();
     }
-    // trailing update: A_IJ -= U_KI^T U_KJ  for K < I <= J  (and the rhs tiles I > K)
+    // trailing update: A_IJ -= U_KI^T U_KJ  for K < I <= J  (and the rhs tiles I > K).  No look-ahead: on gfx950 the
+    // f64 MFMA and f64 VALU share the DP pipe (tools/probe_coexec.hip: 1 MFMA + 12 independent v_fma_f64 = 64 + 64 clk),
+    // so deferring these MFMAs into the VALU stream of the next diagonal block gains nothing (tried, measured).
 #pragma unroll
     for (int I = K + 1; I < NB; ++I) {
 #pragma unroll

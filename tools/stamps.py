@@ -1,0 +1,26 @@
+"""Diagnostic: where does a (segment, cluster) pair spend its cycles?  Uses the HGP_STAMPS build (make stamps)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["HGP_LIB"] = os.path.join(ROOT, "hdpgpc_amd", "lib", "libhdpgpc_hip_stamps.so")
+import hdpgpc_amd._ffi as ffi
+import numpy as np, torch
+from hdpgpc_amd import ops
+from oracle import hdpgpc_oracle as orc
+ffi.lib.hgp_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+dev = lambda a: torch.as_tensor(a, dtype=torch.float64, device="cuda")
+for (N, K, T) in [(2048, 8, 128), (2048, 8, 96)]:
+    b = orc.synthetic_batch(N, K, T)
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    x, y = dev(b["x"]), dev(b["y"])
+    plan.loglik(x, y); torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 8)()
+    ffi.lib.hgp_debug_stamps(buf)           # reset
+    plan.loglik(x, y); torch.cuda.synchronize()
+    ffi.lib.hgp_debug_stamps(buf)
+    v = np.array(list(buf), dtype=np.float64) / (N * K)
+    names = ["d=y-E^T a'", "sweep1 (M'E)", "K** init", "sweep2 (E^T B)", "regularise", "factor+solve", "-", "  of which diag16"]
+    print(f"T={T}: cycles per pair (s_memtime ticks, 100 MHz-independent shader clock)")
+    for nme, val in zip(names, v):
+        print(f"   {nme:18s} {val:10.0f}")
+    print(f"   total              {v[:6].sum():10.0f}")
