@@ -221,12 +221,26 @@ class GPI_model:
             pairs, inv = np.unique(np.stack([g_ci, g_fi], 1), axis=0, return_inverse=True)
             means = ops.gemm_batched(self.C[torch.as_tensor(pairs[:, 0], device=self.device)],
                                      self.f_star[torch.as_tensor(pairs[:, 1], device=self.device)]).reshape(-1, T)
-            im, ia, io, ic = ops.build_items(g_ci.tolist(), np.where(codes % 2 == 1, ini_noise, 0.0).tolist(), counts.tolist())
-            # item -> group -> mean row
-            grp_of_item = np.repeat(np.arange(len(codes)), [-(-c // ops.MAX_CHUNK) for c in counts])
-            quad, _, info = ops.score_groups(Y, means.contiguous(), self.Sigma, im, ia, io, ic, seg_ids=order.astype(np.int32),
-                                             item_mean=inv.reshape(-1)[grp_of_item].astype(np.int32))
-            ops.raise_on_info(info, "compute_sq_err_all")
+            adds = np.where(codes % 2 == 1, ini_noise, 0.0)
+            inv = inv.reshape(-1)
+            quad = torch.zeros(n, dtype=f64, device=self.device)
+            multi = counts > 1
+            if multi.any():   # several segments share one (step, first) state: one factorisation, many right-hand sides
+                gm = np.nonzero(multi)[0]
+                seg_list = np.concatenate([order[start[g]:start[g] + counts[g]] for g in gm]).astype(np.int32)
+                im, ia, io, ic = ops.build_items(g_ci[gm].tolist(), adds[gm].tolist(), counts[gm].tolist())
+                grp_of_item = np.repeat(np.arange(len(gm)), [-(-c // ops.MAX_CHUNK) for c in counts[gm]])
+                quad, _, info = ops.score_groups(Y, means.contiguous(), self.Sigma, im, ia, io, ic, seg_ids=seg_list,
+                                                 item_mean=inv[gm][grp_of_item].astype(np.int32))
+                ops.raise_on_info(info, "compute_sq_err_all")
+            single = ~multi
+            if single.any():  # member segments: each has its own Sigma_i and a single right-hand side
+                gs = np.nonzero(single)[0]
+                segs = torch.as_tensor(rep[gs], device=self.device)
+                q1, _, info1 = ops.score_each(Y[segs].contiguous(), means.contiguous(), self.Sigma, g_ci[gs].astype(np.int32),
+                                              inv[gs].astype(np.int32), adds[gs])
+                ops.raise_on_info(info1, "compute_sq_err_all")
+                quad[segs] = q1
             return -0.5 * quad - 0.5 * T * LOG2PI
         # general path (GPI_model.py:535-545): every segment against the state of ITS step, on its own grid
         pairs, col = np.unique(np.stack([ci_seg, fi_seg], 1), axis=0, return_inverse=True)

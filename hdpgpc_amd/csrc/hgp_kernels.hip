@@ -226,6 +226,63 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_score(ScoreArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------- a6, one state per segment
+// The reference's real dataflow on a shared grid: every member segment i of a cluster is scored against ITS OWN
+// Sigma_i (GPI_model.py:508-531), i.e. one factorisation per segment with a single right-hand side.  Lean variant
+// of k_wave_score: the right-hand side is an LDS vector eliminated on the VALU (no RHS tiles), which brings the
+// NB <= 6 instantiations under 256 registers -> two waves per SIMD, so one matrix's pivot chain overlaps another's
+// loads and MFMAs.  HBM-bound in principle: 8 T^2 + 16 T + 8 bytes per evaluation.
+struct EachArgs {
+  const double* Y;
+  int ldy;
+  const double* mean;
+  long mean_stride;
+  const double* Sigma;
+  long sigma_stride;
+  int T, n;
+  const int32_t* seg_mat;    // [n] Sigma index of segment i
+  const int32_t* seg_mean;   // [n] mean row of segment i (NULL: seg_mat)
+  const double* seg_add;     // [n] additive diagonal (NULL: 0)
+  double jitter_rel;
+  double* out_quad;
+  double* out_logdet;
+  int32_t* out_info;
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES, (NB <= 6) ? 2 : 1) void k_wave_score1(EachArgs a) {
+  __shared__ __attribute__((aligned(16))) double scr_all[WAVES * DIAG_SCR];
+  __shared__ __attribute__((aligned(16))) double dv_all[WAVES * 16 * NB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int seg = blockIdx.x * WAVES + wave;
+  if (seg >= a.n) return;
+  double* scr = scr_all + wave * DIAG_SCR;
+  double* dv = dv_all + wave * 16 * NB;
+  const int T = a.T;
+  const int mat = a.seg_mat[seg];
+  const double* S = a.Sigma + (size_t)mat * a.sigma_stride;
+  const double* mu = a.mean ? a.mean + (size_t)(a.seg_mean ? a.seg_mean[seg] : mat) * a.mean_stride : nullptr;
+  const double* yr = a.Y + (size_t)seg * a.ldy;
+  for (int i = lane; i < 16 * NB; i += 64) dv[i] = (i < T) ? yr[i] - (mu ? mu[i] : 0.0) : 0.0;
+  d4 U[NB * (NB + 1) / 2];
+  d4 Rnone[NB];
+  load_sym_upper<NB>(U, S, T, T, lane);
+  {
+    double sh = a.seg_add ? a.seg_add[seg] : 0.0;
+    if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(diag_abs_mean<NB>(U, T, lane, sh), F64_EPS);
+    if (sh != 0.0) add_diag<NB>(U, sh, T, lane);
+  }
+  __builtin_amdgcn_wave_barrier();
+  PivotAcc pa;
+  pa.init();
+  const double q = wave_factor<NB, 2>(U, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, T);
+  if (lane == 0) {
+    a.out_quad[seg] = q;
+    if (a.out_logdet) a.out_logdet[seg] = pa.logdet();
+    if (a.out_info) a.out_info[seg] = pa.info;
+  }
+}
+
 // ------------------------------------------------------------------ 128 < T <= 256: cooperative kernels
 // One workgroup (4 waves) per matrix / work item; see Coop<> in tile_f64.hpp.
 template <int NB>
@@ -1548,5 +1605,24 @@ int hgp_debug_stamps(unsigned long long* out8_host) {
   return 0;
 }
 #endif
+
+int hgp_score_each_f64(const double* Y, int ldy, const double* mean, long mean_stride, const double* Sigma,
+                       long sigma_stride, int T, const int32_t* seg_mat, const int32_t* seg_mean, const double* seg_add,
+                       int n, double jitter_rel, double* out_quad, double* out_logdet, int32_t* out_info, void* stream) {
+  if (!Y || !Sigma || !seg_mat || !out_quad || T <= 0 || ldy < T || n < 0) return -1;
+  if (n == 0) return 0;
+  if (T > HGP_MAX_T_WAVE) return -2;   // larger T: hgp_score_groups_f64 with one segment per item
+  EachArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, n, seg_mat, seg_mean, seg_add, jitter_rel, out_quad, out_logdet,
+             out_info};
+  dim3 grid((n + WAVES - 1) / WAVES), blk(64 * WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nb_for(T)) {
+    case 2: hipLaunchKernelGGL(k_wave_score1<2>, grid, blk, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_wave_score1<4>, grid, blk, 0, st, a); break;
+    case 6: hipLaunchKernelGGL(k_wave_score1<6>, grid, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL(k_wave_score1<8>, grid, blk, 0, st, a); break;
+  }
+  return launch_status();
+}
 
 }  // extern "C"

@@ -117,6 +117,29 @@ def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids
     return quad, logdet, info
 
 
+def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=1e-8, want_logdet=False, want_info=True):
+    """a6 for member segments: segment i against its own state.  Y [n,T]; mean [S,T]; Sigma [S,T,T]; seg_* [n]."""
+    Y = _dev64(Y, "Y")
+    Sigma = _dev64(Sigma, "Sigma")
+    dev = Y.device
+    n, T = Y.shape
+    if mean is not None:
+        mean = _dev64(mean.reshape(-1, T), "mean")
+
+    def up(a, dt):
+        if a is None:
+            return None
+        return a.to(device=dev, dtype=dt).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+
+    sm, sme, sa = up(seg_mat, torch.int32), up(seg_mean, torch.int32), up(seg_add, torch.float64)
+    quad = torch.zeros(n, dtype=torch.float64, device=dev)
+    logdet = torch.zeros(n, dtype=torch.float64, device=dev) if want_logdet else None
+    info = torch.zeros(n, dtype=torch.int32, device=dev) if want_info else None
+    _ffi.check(_ffi.lib.hgp_score_each_f64(_ptr(Y), T, _ptr(mean), T, _ptr(Sigma), T * T, T, _ptr(sm), _ptr(sme), _ptr(sa), n,
+                                           jitter_rel, _ptr(quad), _ptr(logdet), _ptr(info), _stream()), "score_each")
+    return quad, logdet, info
+
+
 class PairsPlan:
     """a2+a5 for an N x K batch: per-cluster operators (plan) + the per-pair kernel."""
 

@@ -273,3 +273,21 @@ def test_large_T_pairs(T):
     _, q_ref, ld_ref = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"], first_noise=fn)
     assert rel_err(quad.cpu().numpy(), q_ref) < RT_PAIR
     assert rel_err(logdet.cpu().numpy(), ld_ref) < RT_PAIR
+
+
+@pytest.mark.parametrize("T", [8, 33, 90, 128])
+def test_score_each_own_state_per_segment(T):
+    rng = np.random.default_rng(40 + T)
+    n, S = 37, 9
+    Q = rng.normal(size=(S, T, T))
+    Sig = Q @ Q.transpose(0, 2, 1) / T + np.eye(T) + 1e-3 * rng.normal(size=(S, T, T))
+    mean = rng.normal(size=(5, T))
+    Y = rng.normal(size=(n, T)) * 2
+    sm, sme = rng.integers(0, S, n), rng.integers(0, 5, n)
+    add = np.where(rng.random(n) < 0.3, 0.07, 0.0)
+    quad, logdet, info = ops.score_each(dev(Y), dev(mean), dev(Sig), sm.astype(np.int32), sme.astype(np.int32), add, want_logdet=True)
+    assert int(info.abs().max()) == 0
+    for i in range(n):
+        q_ref, ld_ref = orc.quad_logdet(Y[i] - mean[sme[i]], Sig[sm[i]] + add[i] * np.eye(T))
+        assert abs(float(quad[i]) - q_ref) <= RT_WAVE * abs(q_ref)
+        assert abs(float(logdet[i]) - ld_ref) <= 1e-10 * max(1.0, abs(ld_ref))

@@ -37,3 +37,11 @@ for (N,K,T) in [(256,16,256)]:
     tu = timeit(lambda: plan.update(xb,mean,Sig), n=2, w=1)
     tp = timeit(lambda: plan.loglik(x,y), n=2, w=1)
     print(f"pairs (staged, large T) N={N} K={K} T={T}: update {tu*1e3:.3f} ms, pairs {tp*1e3:.3f} ms -> {N*K/(tu+tp):.3e} evals/s", flush=True)
+
+for (S,T) in [(4096,128),(4096,90),(4096,64),(16384,90)]:
+    rng=np.random.default_rng(0)
+    Q=rng.normal(size=(64,T,T)); A=Q@Q.transpose(0,2,1)/T+np.eye(T)
+    Sig=dev(np.tile(A,(S//64,1,1))); Y=dev(rng.normal(size=(S,T))); mean=dev(rng.normal(size=(S,T)))
+    sm=torch.arange(S,dtype=torch.int32,device="cuda")
+    t=timeit(lambda: ops.score_each(Y,mean,Sig,sm))
+    print(f"score_each   S={S} T={T}: {t*1e3:.3f} ms -> {S/t:.3e} evals/s, {S*T*T*8/t/1e9:.1f} GB/s", flush=True)
