@@ -744,6 +744,7 @@ struct PrepFinalArgs {
   int T, TP;
   double* Mp;           // [K,TP,TP]
   double* ap;           // [K,TP]
+  int interleave;       // 1: tile-pair interleaved columns (fused pairs kernel); 0: plain row-major (staged large-T path)
 };
 
 __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
@@ -753,8 +754,25 @@ __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
   const double* Q = a.Q + (size_t)k * TP * TP;
   const double* Ki = a.Kinv + (size_t)k * TP * TP;
   double* Mp = a.Mp + (size_t)k * TP * TP;
+  // Column order of M' (physical jp -> logical j).  The pairs kernel reads row k of M' as the A operands of the NH
+  // row tiles of one half h (tiles NH h .. NH h + NH - 1): inside a half, tiles are interleaved two by two so that ONE
+  // 16-byte load per lane (lane cc) yields the operands of tiles 2q and 2q + 1; an odd last tile stays contiguous.
+  const int NHh = (TP / 16) / 2;
   for (int idx = blockIdx.y * 256 + tid; idx < TP * TP; idx += gridDim.y * 256) {
-    int i = idx / TP, j = idx % TP;
+    int i = idx / TP, jp = idx % TP;
+    const int hh = jp / (16 * NHh), loc = jp % (16 * NHh);
+    int tl, cc;
+    if (!a.interleave) {
+      tl = loc / 16;
+      cc = loc % 16;
+    } else if (loc < 32 * (NHh / 2)) {
+      tl = 2 * (loc / 32) + (loc & 1);
+      cc = (loc % 32) >> 1;
+    } else {
+      tl = NHh - 1;
+      cc = loc - 16 * (NHh - 1);
+    }
+    const int j = 16 * (NHh * hh + tl) + cc;
     double v = 0.0;
     if (i < T && j < T) v = (c * c) * (0.5 * (Q[(size_t)i * TP + j] + Q[(size_t)j * TP + i]) - 0.5 * (Ki[(size_t)i * TP + j] + Ki[(size_t)j * TP + i]));
     Mp[idx] = v;
@@ -953,7 +971,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     d4 cov[NB * (NB + 1) / 2];
     // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
     // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
-    const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP + c;
+    const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP;   // + column offset inside HGP_FILL (interleaved)
     // Sweep-1 operand ring: 4 slots of half a k-block each (2 k-steps: 2 x NH rows of M' from L2 + 2 values of E
     // from LDS).  A slot is refilled right after its MFMAs are issued, i.e. three half-blocks (about 1.5k cycles
     // of MFMA) before it is used again; the first two blocks of the NEXT sweep are requested at the end of a sweep.
@@ -961,8 +979,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     int kA = -1, kB = -1, m = msk[0];
 #define HGP_FILL(slot, half, blk, Mptr, Jcol)                                                               \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                        \
-    _Pragma("unroll") for (int I_ = 0; I_ < NH; ++I_)                                                       \
-      ra[slot][s_][I_] = (Mptr)[(size_t)(16 * (blk) + 4 * (2 * (half) + s_)) * TP + 16 * I_];               \
+    const double* row_ = (Mptr) + (size_t)(16 * (blk) + 4 * (2 * (half) + s_)) * TP;                        \
+    _Pragma("unroll") for (int P_ = 0; P_ < NH / 2; ++P_) {                                                 \
+      const d2 t_ = *reinterpret_cast<const d2*>(row_ + 32 * P_ + 2 * c);                                   \
+      ra[slot][s_][2 * P_] = t_[0];                                                                         \
+      ra[slot][s_][2 * P_ + 1] = t_[1];                                                                     \
+    }                                                                                                       \
+    if (NH & 1) ra[slot][s_][NH - 1] = row_[16 * (NH - 1) + c];                                             \
     re[slot][s_] = E[(16 * (blk) + 4 * (2 * (half) + s_) + g) * TP + 16 * (Jcol) + c];                      \
   }
 #define HGP_MMA(slot)                                                                                       \
@@ -1428,7 +1451,7 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   launch_gemm(g1, K, st);
   launch_gemm(g2, K, st);
   launch_gemm(g3, K, st);
-  PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap};
+  PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap, p->big ? 0 : 1};
   hipLaunchKernelGGL(k_prep_final, dim3(K, 8), dim3(256), 0, st, fin);
   return launch_status();
 }

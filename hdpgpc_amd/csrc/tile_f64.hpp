@@ -30,6 +30,7 @@
 namespace hgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int DIAG_LD = 18;              // row stride (doubles) of the per-wave 16x16 LDS staging tile
 constexpr int DIAG_SCR = 16 * DIAG_LD;   // doubles of LDS scratch each wave needs
