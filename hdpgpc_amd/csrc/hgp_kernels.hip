@@ -1315,8 +1315,8 @@ int hgp_gram_rbf_f64(const double* x, int nx, const double* y, int ny, double c,
 
 int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add_diag, double* Linv, double* logdet,
                           int32_t* info, void* stream) {
-  if (!A || T <= 0 || b < 0) return -1;
   if (b == 0) return 0;
+  if (!A || T <= 0 || b < 0) return -1;
   if (T > HGP_MAX_T_COOP) return -2;
   PotrfArgs a{A, T, b, jitter_rel, add_diag, Linv, logdet, info};
   if (T > HGP_MAX_T_WAVE) return T <= 192 ? launch_coop_potrf<12>(a, (hipStream_t)stream) : launch_coop_potrf<16>(a, (hipStream_t)stream);
@@ -1336,8 +1336,8 @@ int hgp_score_groups_f64(const double* Y, int ldy, const double* mean, long mean
                          const double* item_add, const int32_t* item_off, const int32_t* item_cnt, int n_items,
                          const int32_t* seg_ids, double jitter_rel, double* out_quad, double* out_logdet,
                          int32_t* out_info, void* stream) {
-  if (!Y || !Sigma || !item_mat || !item_off || !item_cnt || !out_quad || T <= 0 || ldy < T || n_items < 0) return -1;
   if (n_items == 0) return 0;
+  if (!Y || !Sigma || !item_mat || !item_off || !item_cnt || !out_quad || T <= 0 || ldy < T || n_items < 0) return -1;
   if (T > HGP_MAX_T_COOP) return -2;
   ScoreArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, T, item_mat, item_mean, item_add, item_off, item_cnt, n_items,
               seg_ids, jitter_rel, out_quad, out_logdet, out_info};
@@ -1459,8 +1459,8 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
 int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double* y, int N, int Ts,
                          const double* first_noise, const int32_t* sel, double* out_quad, double* out_logdet,
                          int32_t* out_info, void* stream) {
+  if (N == 0) return 0;   // an empty batch is a no-op (its pointers may legitimately be null)
   if (!p || !x || !y || !out_quad || N < 0 || Ts <= 0) return -1;
-  if (N == 0) return 0;
   if (Ts > HGP_MAX_T_COOP) return -2;
   if (tp_for(Ts) > p->TP) return -2;   // plan was created with a smaller Ts_max
   hipStream_t st = (hipStream_t)stream;
@@ -1632,8 +1632,8 @@ int hgp_debug_stamps(unsigned long long* out8_host) {
 int hgp_score_each_f64(const double* Y, int ldy, const double* mean, long mean_stride, const double* Sigma,
                        long sigma_stride, int T, const int32_t* seg_mat, const int32_t* seg_mean, const double* seg_add,
                        int n, double jitter_rel, double* out_quad, double* out_logdet, int32_t* out_info, void* stream) {
-  if (!Y || !Sigma || !seg_mat || !out_quad || T <= 0 || ldy < T || n < 0) return -1;
   if (n == 0) return 0;
+  if (!Y || !Sigma || !seg_mat || !out_quad || T <= 0 || ldy < T || n < 0) return -1;
   if (T > HGP_MAX_T_WAVE) return -2;   // larger T: hgp_score_groups_f64 with one segment per item
   EachArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, n, seg_mat, seg_mean, seg_add, jitter_rel, out_quad, out_logdet,
              out_info};

@@ -1,0 +1,127 @@
+"""Edge cases of the C-ABI / host layer on the GPU: empty batches, tiny and ragged sizes, one cluster,
+non-positive-definite inputs (LAPACK-style info -> torch.linalg.LinAlgError), argument validation."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import hdpgpc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from hdpgpc_amd import _ffi, ops
+    from hdpgpc_amd.GPI import RBFWhiteKernel
+    from hdpgpc_amd.GPI_model import GPI_model
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def test_empty_batches_are_noops():
+    T = 24
+    b = orc.synthetic_batch(1, 2, T, seed=1)
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    quad, logdet, info = plan.loglik(torch.empty((0, T), dtype=torch.float64, device="cuda"),
+                                     torch.empty((0, T), dtype=torch.float64, device="cuda"))
+    assert quad.shape == (0, 2) and logdet.shape == (0, 2)
+    L, info = ops.potrf_batched(torch.empty((0, T, T), dtype=torch.float64, device="cuda"))
+    assert L.shape == (0, T, T)
+    q, _, _ = ops.score_each(torch.empty((0, T), dtype=torch.float64, device="cuda"), None, dev(np.eye(T)[None]),
+                             np.zeros(0, np.int32))
+    assert q.numel() == 0
+
+
+@pytest.mark.parametrize("T", [1, 2, 15, 16, 17, 31, 100, 127])
+def test_sizes_that_are_not_multiples_of_the_tile(T):
+    rng = np.random.default_rng(T)
+    Q = rng.normal(size=(2, T, T))
+    A = Q @ Q.transpose(0, 2, 1) + T * np.eye(T)
+    L, info, logdet = ops.potrf_batched(dev(A), 0.0, 0.0, want_logdet=True)
+    assert int(info.abs().max()) == 0
+    for k in range(2):
+        ref = np.linalg.cholesky(A[k])
+        assert np.allclose(L[k].cpu().numpy(), ref, rtol=1e-11, atol=1e-12)
+        assert abs(float(logdet[k]) - 2 * np.log(np.diag(ref)).sum()) <= 1e-10 * max(1.0, T)
+    if T >= 2:
+        b = orc.synthetic_batch(3, 2, T, seed=T)
+        plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+        quad, logdet2, info2 = plan.loglik(dev(b["x"]), dev(b["y"]))
+        _, q_ref, ld_ref = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
+        assert int(info2.abs().max()) == 0
+        assert rel_err(quad.cpu().numpy(), q_ref) < 1e-8 and rel_err(logdet2.cpu().numpy(), ld_ref) < 1e-8
+
+
+def test_segment_grid_longer_and_shorter_than_the_basis():
+    """T* != T: the plan is padded to the larger of the two (e.g. scoring on a resampled grid)."""
+    T, K = 40, 2
+    b = orc.synthetic_batch(4, K, T, seed=3)
+    for Ts in (25, 64):
+        rng = np.random.default_rng(Ts)
+        x = np.sort(rng.uniform(0, T - 1, size=(4, Ts)), axis=1)
+        y = rng.normal(size=(4, Ts)) * 3
+        plan = ops.PairsPlan(T, Ts, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+        quad, logdet, info = plan.loglik(dev(x), dev(y))
+        _, q_ref, ld_ref = orc.loglik_pairs(x, y, b["xb"], b["theta"], b["mean"], b["Sigma"])
+        assert int(info.abs().max()) == 0
+        assert rel_err(quad.cpu().numpy(), q_ref) < 1e-8 and rel_err(logdet.cpu().numpy(), ld_ref) < 1e-8
+
+
+def test_single_cluster_single_segment():
+    b = orc.synthetic_batch(1, 1, 20, seed=4)
+    plan = ops.PairsPlan(20, 20, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    quad, _, _ = plan.loglik(dev(b["x"]), dev(b["y"]))
+    _, q_ref, _ = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
+    assert rel_err(quad.cpu().numpy(), q_ref) < 1e-8
+
+
+def test_not_positive_definite_raises_like_torch():
+    T = 20
+    kern = RBFWhiteKernel(5.0, 1.2, 0.5)
+    m = GPI_model(kern, np.arange(float(T))[:, None])
+    bad = np.eye(T)
+    bad[7, 7] = -3.0
+    with pytest.raises(torch.linalg.LinAlgError):
+        m._chol_spd(bad)
+    with pytest.raises(torch.linalg.LinAlgError):
+        m._gaussian_score_shared_cov(np.zeros((2, T)), np.zeros(T), bad)
+    # the info value is LAPACK's: index (1-based) of the first non-positive pivot
+    _, info = ops.potrf_batched(dev(bad[None]), 0.0, 0.0)
+    assert int(info[0]) == 8
+    # NaN input is reported, not silently propagated as "ok"
+    bad2 = np.eye(T)
+    bad2[3, 3] = np.nan
+    _, info = ops.potrf_batched(dev(bad2[None]), 0.0, 0.0)
+    assert int(info[0]) > 0
+
+
+def test_argument_validation_returns_status_codes():
+    lib = _ffi.lib
+    z = ctypes.c_void_p(0)
+    assert lib.hgp_potrf_batched_f64(z, 8, 1, 0.0, 0.0, z, z, z, z) == -1
+    assert lib.hgp_potrf_batched_f64(ctypes.c_void_p(16), 4096, 1, 0.0, 0.0, z, z, z, z) == -2     # T beyond every kernel
+    assert lib.hgp_chol_rank1_f64(ctypes.c_void_p(16), ctypes.c_void_p(16), z, z, 300, 1, z, z) == -2
+    with pytest.raises(NotImplementedError):
+        ops.PairsPlan(300, 300, np.array([[1.0, 1.0, 0.1]]))
+    with pytest.raises(ValueError):
+        ops.PairsPlan(16, 16, np.array([[1.0, -1.0, 0.1]]))                                       # negative length-scale
+    with pytest.raises(TypeError):
+        ops.gram_rbf(torch.zeros(4), None, 1.0, 1.0)                                               # CPU tensor: no fallback
+
+
+def test_many_right_hand_sides_one_factor():
+    """a4 with B >> 64: the group is split into work items that each refactor once (GPI_model.py:531 with B = N)."""
+    rng = np.random.default_rng(11)
+    T, B = 90, 1000
+    Q = rng.normal(size=(T, T))
+    cov = Q @ Q.T / T + np.eye(T)
+    mean = rng.normal(size=T)
+    Y = rng.normal(size=(B, T)) * 2
+    items = ops.build_items([0], [0.0], [B])
+    quad, _, info = ops.score_groups(dev(Y), dev(mean), dev(cov), *items)
+    assert int(info.abs().max()) == 0
+    ref = -2.0 * (orc.gaussian_score_shared_cov(Y, mean, cov) + 0.5 * T * orc.LOG2PI)
+    assert rel_err(quad.cpu().numpy(), ref) < 1e-10
