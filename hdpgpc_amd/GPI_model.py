@@ -5,8 +5,14 @@ reference (f_star[i], Sigma[i], ... one entry per LDS step) are held as STACKED 
 ([steps, T, 1] / [steps, T, T]) so that a whole batch of steps is scored by one kernel launch.  Indexing
 ``model.Sigma[i]`` / ``[-1]`` / ``len(model.Sigma)`` behaves like the reference's lists.
 
-The producer of that state (the Kalman / RTS / MNIW recursion, GPI_model.py:325-406,966-1115) is outside this
-hot path; state arrives through ``load_state``.
+State arrives either through ``load_state`` (arrays captured elsewhere) or from the producer half below
+(first "next" row): ``full_pass_weighted`` = per member Kalman update (GPI.py:72-151), two-step RTS
+(GPI.py:272-300), MNIW conjugate update (GPI_model.py:966-1115,1300-1344), then the full RTS pass (GPI.py:240-270).
+It is a composition of the batched MFMA GEMM and Cholesky-inverse kernels, one launch per matrix operation - the
+persistent chain kernel of SURVEY.md H5 is the next step.  Every linear solve of the reference (LU ``torch.linalg.solve``
+/ ``inv`` of symmetric positive-definite matrices) is done through the Cholesky inverse; covered cases: dynamic
+model, shared grid, h = 1 (what hdpgpc/tests run with warp=False).  The gpytorch hyper-parameter fit is NOT built:
+``fit_kernel_params`` takes theta from ``GPI_model.fixed_theta`` (parity-unpinned piece).
 """
 import math
 
@@ -28,6 +34,40 @@ class matrix_normal_inv_wishart:
         self.m_r_cov = m_r_cov
         self.n0 = n0
         self.scale = scale
+
+    def get_mean(self):
+        return self.m_mean
+
+    def get_scale(self, final=False):
+        return self.scale if final else self.scale * self.n0 / (self.n0 - 2)
+
+    def set_scale(self, scale):
+        self.scale = scale
+
+    def posterior(self, n_k, y1, y2, cov=None, cov_=None, cov_cross=None, sse_matrix=None, annealing=False):
+        """GPI_model.py:1300-1344 for n_k = 1, zero covariance corrections and no projection (the only call the
+        one-step estimation makes on a shared grid, GPI_model.py:995-998,1034-1036)."""
+        if n_k != 1 or sse_matrix is not None:
+            raise NotImplementedError("MNIW posterior: only the one-step, shared-grid update is built")
+        T = self.scale.shape[0]
+        dev = self.scale.device
+        eye = torch.eye(T, dtype=f64, device=dev)
+        new_n0 = self.n0 + n_k
+        jitter = 1e-2 * max(float(torch.mean(torch.diagonal(self.scale).abs())), np.finfo(np.float64).eps)
+        m_r_cov = eye if self.m_r_cov is None else self.m_r_cov
+        _, info, Z = ops.potrf_batched(m_r_cov.contiguous(), 0.0, jitter, want_inv=True)       # :1313-1316
+        ops.raise_on_info(info, "MNIW.posterior")
+        scale_inv = ops.gemm_batched(Z[0], Z[0], transA=True)
+        y1, y2 = y1.reshape(T, 1), y2.reshape(T, 1)
+        S__ = ops.gemm_batched(y2, y2, transB=True) + scale_inv                                 # :1321,1325
+        S_ = ops.gemm_batched(y1, y2, transB=True) + ops.gemm_batched(self.m_mean.contiguous(), scale_inv)
+        _, info, Zs = ops.potrf_batched(S__.contiguous(), 0.0, 1e-8, want_inv=True)             # :1329
+        ops.raise_on_info(info, "MNIW.posterior")
+        part_mean = ops.gemm_batched(ops.gemm_batched(S_.contiguous(), Zs[0], transB=True), Zs[0])   # S_ S__^{-1}
+        new_m_mean = ((self.n0 - 2) * self.m_mean + part_mean) / (new_n0 - 2)                   # :1332-1336
+        e = y1 - y2
+        new_scale = ((self.n0 - 2) * self.scale + ops.gemm_batched(e, e, transB=True)) / (new_n0 - 2)
+        return matrix_normal_inv_wishart(new_m_mean, S__, new_n0, new_scale)
 
     def log_likelihood_MNIW(self, M, Sigma, n0=None):
         T = M.shape[0]
@@ -55,9 +95,16 @@ class GPI_model:
         self.bayesian = bayesian
         self.annealing = annealing
         self.verbose = verbose
-        self.f_star = self.f_star_sm = self.cov_f_sm = self.A = self.Gamma = self.C = self.Sigma = None
+        self.f_star, self.f_star_sm, self.cov_f, self.cov_f_sm = [], [], [], []
+        self.A, self.Gamma, self.C, self.Sigma = [], [], [], []
+        self.x_train, self.y_train = [], []
         self.A_def = self.Gamma_def = self.C_def = self.Sigma_def = None
-        self.internal_params = None
+        self.ini_cov_def = None
+        self.internal_params = self.observation_params = None
+        self.fitted = False
+        self.fixed_theta = None        # (c, ell, noise) taken by fit_kernel_params instead of the gpytorch fit
+        self.noise_bounds = (1e-10, 1e10)
+        self._stk = {}
 
     # ------------------------------------------------------------------ state (a12)
     def cond_to_torch(self, x):
@@ -76,8 +123,11 @@ class GPI_model:
         def mat(a):
             return None if a is None else self.cond_to_torch(a).reshape(-1, T, T).contiguous()
 
-        self.f_star, self.f_star_sm = vec(f_star), vec(f_star_sm)
-        self.Sigma, self.C, self.A, self.Gamma, self.cov_f_sm = mat(Sigma), mat(C), mat(A), mat(Gamma), mat(cov_f_sm)
+        unb = lambda t: [] if t is None else list(t.unbind(0))  # noqa: E731
+        self.f_star, self.f_star_sm = unb(vec(f_star)), unb(vec(f_star_sm))
+        self.Sigma, self.C, self.A, self.Gamma, self.cov_f_sm = (unb(mat(Sigma)), unb(mat(C)), unb(mat(A)), unb(mat(Gamma)),
+                                                                 unb(mat(cov_f_sm)))
+        self._stk = {}
         self.indexes = [int(i) for i in indexes]
         self.N = len(self.indexes)
         one = lambda a: None if a is None else self.cond_to_torch(a).reshape(T, T).contiguous()  # noqa: E731
@@ -85,6 +135,14 @@ class GPI_model:
         if n0 is not None:
             self.internal_params = matrix_normal_inv_wishart(self.A_def, None, n0, self.Gamma_def)
         return self
+
+    def _S(self, name):
+        """Stacked [steps, ...] device tensor of one of the per-step lists (cached until the list grows)."""
+        lst = getattr(self, name)
+        key = self._stk.get(name)
+        if key is None or key[0] != len(lst) or key[1] is not lst[-1]:
+            self._stk[name] = (len(lst), lst[-1], torch.stack(lst).contiguous())
+        return self._stk[name][2]
 
     # ------------------------------------------------------------------ a7: which state does step t read?
     def _select(self, t):
@@ -132,6 +190,212 @@ class GPI_model:
             mean, C, Sigma = (self.cond_to_torch(params[0]).reshape(-1, 1), self.cond_to_torch(params[2]).contiguous(),
                               self.cond_to_torch(params[3]))
         return self.gp.pred_dist(x_post, self.x_basis, ops.gemm_batched(C, mean), Sigma)
+
+    # ------------------------------------------------------------------ 8f-1: the producer of the state
+    def _eye(self):
+        T = self.x_basis.shape[0]
+        return torch.eye(T, dtype=f64, device=self.device)
+
+    def compute_mean(self):
+        return torch.zeros((self.x_basis.shape[0], 1), dtype=f64, device=self.device)
+
+    def GPR_dynamic(self, gamma=None, sigma=None):
+        """GPI_model.py:191-204."""
+        eye = self._eye()
+        return eye.clone(), (0.01 if gamma is None else gamma) * eye, eye.clone(), (0.25 if sigma is None else sigma) * eye
+
+    def GPR_static(self, ini_Sigma=None):
+        """GPI_model.py:178-189."""
+        eye = self._eye()
+        return eye.clone(), torch.zeros_like(eye), eye.clone(), (0.25 if ini_Sigma is None else ini_Sigma) * eye
+
+    def initial_conditions(self, ini_mean=None, ini_cov=None, ini_A=None, ini_Gamma=None, ini_C=None, ini_Sigma=None):
+        """GPI_model.py:115-175."""
+        K = self.gp.kernel(self.x_basis, self.x_basis)
+        m0 = self.compute_mean() if ini_mean is None else self.cond_to_torch(ini_mean).reshape(-1, 1)
+        c0 = K if ini_cov is None else self.cond_to_torch(ini_cov)
+        self.f_star, self.f_star_sm = [m0], [m0]
+        self.cov_f, self.cov_f_sm = [c0], [c0]
+        self.ini_cov_def = c0.clone()
+        if ini_A is None and ini_Gamma is None and ini_C is None and ini_Sigma is None:
+            ini_A, ini_Gamma, ini_C, ini_Sigma = self.GPR_dynamic()
+        ini_A, ini_Gamma, ini_C, ini_Sigma = (self.cond_to_torch(m).contiguous() for m in (ini_A, ini_Gamma, ini_C, ini_Sigma))
+        self.A, self.Gamma, self.C, self.Sigma = [ini_A], [ini_Gamma], [ini_C], [ini_Sigma]
+        self.A_def, self.Gamma_def, self.C_def, self.Sigma_def = ini_A, ini_Gamma, ini_C, ini_Sigma
+        self.indexes, self.N, self.x_train, self.y_train, self._stk = [], 0, [], [], {}
+        self.internal_params = matrix_normal_inv_wishart(ini_A, None, self.free_deg_MNIV, ini_Gamma)
+        self.observation_params = matrix_normal_inv_wishart(ini_C, None, self.free_deg_MNIV, ini_Sigma)
+
+    def fit_kernel_params(self, x_train, y, alpha_ini, gamma_ini, valid=True):
+        """GPI_model.py:207-241 with the gpytorch fit (GPI.py:610-770) replaced by ``self.fixed_theta``: what the fit
+        leaves behind is outputscale, a length-scale forced to 1.2 (GPI.py:711) and a noise level clamped to its
+        bounds - and none of them enters Sigma, which is reset to the INITIAL sigma (GPI_model.py:215-219)."""
+        if valid:
+            if self.fixed_theta is None:
+                raise NotImplementedError("kernel hyper-parameter fit (gpytorch) is out of scope: set GPI_model.fixed_theta")
+            c, ell, noise = self.fixed_theta
+            lo, hi = self.noise_bounds
+            k = self.gp.kernel
+            k.constant_value, k.length_scale, k.noise_level = float(c), float(ell), float(min(max(noise, lo), hi))
+            self.gp.fitted = True
+        eye = self._eye()
+        alph = alpha_ini[0][0]
+        self.Sigma[-1] = alph * eye
+        self.Sigma_def = self.Sigma[-1].clone()
+        self.C[-1], self.A[-1] = eye.clone(), eye.clone()
+        self.Gamma[-1] = torch.mean(torch.diagonal(self.Gamma[-1])) * eye
+        self.f_star[-1] = self.f_star_sm[-1] = self.compute_mean()
+        ini_cov = self.gp.kernel(self.x_basis, self.x_basis)
+        self.ini_cov_def = ini_cov
+        self.cov_f[-1] = self.cov_f_sm[-1] = ini_cov
+        self.observation_params.set_scale(alph * eye)
+        self.observation_params.m_mean = self.C[-1]
+        self.internal_params.set_scale(self.Gamma[-1])
+        self.internal_params.m_mean = self.A[-1]
+        self.fitted = True
+        self._stk = {}
+        return self.x_basis, ini_cov
+
+    @staticmethod
+    def _spd_inv(S, what):
+        """S^{-1} of a symmetric positive-definite matrix through the Cholesky inverse: Z^T Z with Z = chol(S)^{-1}."""
+        _, info, Z = ops.potrf_batched(S.contiguous(), 0.0, 0.0, want_inv=True)
+        ops.raise_on_info(info, what)
+        return ops.gemm_batched(Z[0], Z[0], transA=True)
+
+    def _posterior(self, mean_prior, cov_prior, y, A, Gamma, C, Sigma, first_step, h=1.0):
+        """GPI.posterior (GPI.py:72-151) on the shared grid (x_warped == x_basis, K_cov = I)."""
+        mm = ops.gemm_batched
+        xm = mm(A, mean_prior)
+        if first_step:   # cov_prior is the kernel Gram itself (GPI.py:136-139): prior predictive, white-noise observation
+            P = cov_prior
+            f_star = torch.zeros_like(xm)
+            k = self.gp.kernel   # kernel(x) - kernel(x, x): the white-noise level as the reference's subtraction leaves it
+            cov_f = (((k.constant_value + k.noise_level) - k.constant_value) / h) * self._eye()
+        else:
+            P = mm(mm(A, cov_prior), A, transB=True) + Gamma
+            f_star, cov_f = mm(C, xm), Sigma                  # pred_dist short-circuits on the shared grid (GPI.py:467-468)
+        S = mm(mm(C, P), C, transB=True) + cov_f
+        K_t = mm(mm(P, C, transB=True), self._spd_inv(0.5 * (S + S.T), "posterior"))          # P C^T S^{-1}  (GPI.py:144-145)
+        mean_post = xm + mm(K_t, y - f_star)
+        IKC = self._eye() - mm(K_t, C)
+        cov_post = mm(mm(IKC, P), IKC, transB=True) + mm(mm(K_t, cov_f.contiguous()), K_t, transB=True)   # Joseph form
+        return mean_post, cov_post
+
+    def include_sample(self, index, x_train, y, x_warped=None, h=1.0, posterior=True, embedding=True, include_index=False):
+        """GPI_model.py:325-351."""
+        y = self.cond_to_torch(y).reshape(-1, 1)
+        if posterior:
+            self.N += 1
+            self.indexes.append(int(index))
+            self.x_train.append(x_train)
+            self.y_train.append(y)
+            # GPI.py:136 tests cov_prior == ker(xb, xb) on every call (two Gram builds per step); it can only hold for
+            # the first member after the kernel fit, so it is only evaluated there
+            first = self.N == 1 and bool(torch.equal(self.cov_f_sm[-1], self.gp.kernel(self.x_basis, self.x_basis)))
+            f, c = self._posterior(self.f_star_sm[-1], self.cov_f_sm[-1], y, self.A[-1], self.Gamma[-1], self.C[-1],
+                                   self.Sigma[-1] / h, first, h)
+        elif include_index:
+            self.indexes.append(int(index))
+            self.x_train.append(x_train)
+            self.y_train.append(y)
+            f, c = self.f_star_sm[-1], self.cov_f_sm[-1]
+        else:
+            return self.f_star_sm[-1], self.cov_f_sm[-1]
+        self.f_star.append(f), self.f_star_sm.append(f), self.cov_f.append(c), self.cov_f_sm.append(c)
+        return f, c
+
+    def include_weighted_sample(self, index, x_train, x_warped, y, h, snr=None):
+        """GPI_model.py:353-375 (h = 1 or h < 1; snr gating not built)."""
+        if snr is not None:
+            raise NotImplementedError("snr-gated inclusion (multi-lead) is not part of this path")
+        x_train = self.cond_to_torch(x_train).reshape(-1, 1)
+        if not torch.equal(x_train, self.x_basis):
+            raise NotImplementedError("producer recursion: shared grid only")
+        if h == 1.0:
+            if self.N == 0 and not self.fitted:
+                self.fit_kernel_params(x_train, y, self.Sigma[-1], self.Gamma[-1], valid=self.fixed_theta is not None)
+            self.include_sample(index, x_train, y, x_warped, h=1.0)
+        else:
+            self.include_sample(index, x_train, y, x_warped, posterior=False)
+        return self.x_basis
+
+    def backwards_pair(self, h, snr=None):
+        """GPI_model.py:705-716 + GPI.backward_notrange (GPI.py:272-300): smooth the last two filtered states."""
+        if len(self.indexes) > 1 and h == 1.0:
+            mm = ops.gemm_batched
+            A, Gam = self.A[-1], self.Gamma[-1]
+            m0, m1, c0, c1 = self.f_star[-2], self.f_star[-1], self.cov_f[-2], self.cov_f[-1]
+            P = mm(mm(A, c0), A, transB=True) + Gam
+            J = mm(mm(c0, A, transB=True), self._spd_inv(0.5 * (P + P.T), "backwards_pair"))     # c0 A^T P^{-1}
+            self.f_star_sm[-2] = m0 + mm(J, m1 - mm(A, m0))
+            self.cov_f_sm[-2] = c0 + mm(mm(J, c1 - P), J, transB=True)
+            self.f_star_sm[-1], self.cov_f_sm[-1] = m1, c1
+
+    def bayesian_new_params(self, h, model_type="dynamic", full_data=False, q=None, force=False, snr=1.0):
+        """GPI_model.py:966-1115, one-step estimation (full_data=False), dynamic model, shared grid."""
+        if full_data or h != 1.0:
+            raise NotImplementedError("bayesian_new_params: only the one-step update with h = 1 is built")
+        if 1 < self.N < self.estimation_limit or force:
+            try:
+                new_int = self.internal_params.posterior(1, self.f_star_sm[-1], self.f_star_sm[-2])
+                new_obs = self.observation_params.posterior(1, self.y_train[-1], self.f_star_sm[-1])
+            except torch.linalg.LinAlgError:            # GPI_model.py:1068-1071: keep the previous distributions
+                new_int, new_obs = self.internal_params, self.observation_params
+        else:
+            new_int, new_obs = self.internal_params, self.observation_params
+        self.internal_params, self.observation_params = new_int, new_obs
+        if 1 < self.N:
+            Gamma_, Sigma_ = new_int.get_scale(), new_obs.get_scale()
+        else:
+            Gamma_, Sigma_ = self.Gamma[-1], self.Sigma[-1]
+        if self.annealing:                               # GPI_model.py:1083-1091
+            Gamma_ = Gamma_ + self.Gamma[0] / (self.N ** 2)
+            Sigma_ = Sigma_ + self.Sigma[0] / (self.N ** 2)
+        if self.N < self.estimation_limit:
+            self.A.append(new_int.get_mean())
+            self.Gamma.append(Gamma_)
+            self.C.append(new_obs.get_mean())
+            self.Sigma.append(Sigma_)
+
+    def backwards(self, h=1.0):
+        """GPI_model.py:687-703 + GPI.backward (GPI.py:240-270): full RTS pass over the filtered states."""
+        if h != 1.0:
+            return
+        mm = ops.gemm_batched
+        means, covs = list(self.f_star[1:]), list(self.cov_f[1:])
+        A_list, G_list = self.A[1:], self.Gamma[1:]
+        for t in range(len(means) - 2, -1, -1):
+            A = A_list[t] if t < len(A_list) else A_list[-1]
+            Gam = G_list[t] if t < len(G_list) else G_list[-1]
+            P = mm(mm(A, covs[t]), A, transB=True) + Gam
+            J = mm(mm(covs[t], A, transB=True), self._spd_inv(0.5 * (P + P.T), "backwards"))
+            means[t] = means[t] + mm(J, means[t + 1] - mm(A, means[t]))
+            covs[t] = covs[t] + mm(mm(J, covs[t + 1] - P), J, transB=True)
+        for i in range(len(means)):
+            self.f_star_sm[i + 1] = means[i]
+            self.cov_f_sm[i + 1] = covs[i]
+        self._stk = {}
+
+    def full_pass_weighted(self, x_trains, y_trains, resp, q=None, q_lat=None, snr=None):
+        """GPI_model.py:377-406: filter / smooth / re-estimate over the members (resp > 0.99), then score everything."""
+        x_trains = self.cond_to_torch(x_trains)
+        y_trains = self.cond_to_torch(y_trains)
+        resp = torch.as_tensor(resp)
+        dynamic = bool(torch.any(self.Gamma[-1] != 0))
+        active = torch.nonzero(resp > 0.99, as_tuple=False).reshape(-1).tolist()
+        if len(active) == 0:
+            return q, q_lat
+        for index in active:
+            h = float(resp[index])
+            self.include_weighted_sample(index, x_trains[index], x_trains[index], y_trains[index], h)
+            if dynamic:
+                self.backwards_pair(h)
+                self.bayesian_new_params(h)
+        if dynamic:
+            self.backwards()
+        self._stk = {}
+        return self.compute_sq_err_all(x_trains, y_trains), self.compute_q_lat_all(x_trains)
 
     # ------------------------------------------------------------------ a3 / a4
     def _chol_spd(self, M, jitter_scale=1e-8):
@@ -219,8 +483,8 @@ class GPI_model:
             rep = order[start]
             g_ci, g_fi = ci_seg[rep], fi_seg[rep]
             pairs, inv = np.unique(np.stack([g_ci, g_fi], 1), axis=0, return_inverse=True)
-            means = ops.gemm_batched(self.C[torch.as_tensor(pairs[:, 0], device=self.device)],
-                                     self.f_star[torch.as_tensor(pairs[:, 1], device=self.device)]).reshape(-1, T)
+            means = ops.gemm_batched(self._S("C")[torch.as_tensor(pairs[:, 0], device=self.device)],
+                                     self._S("f_star")[torch.as_tensor(pairs[:, 1], device=self.device)]).reshape(-1, T)
             adds = np.where(codes % 2 == 1, ini_noise, 0.0)
             inv = inv.reshape(-1)
             quad = torch.zeros(n, dtype=f64, device=self.device)
@@ -230,14 +494,14 @@ class GPI_model:
                 seg_list = np.concatenate([order[start[g]:start[g] + counts[g]] for g in gm]).astype(np.int32)
                 im, ia, io, ic = ops.build_items(g_ci[gm].tolist(), adds[gm].tolist(), counts[gm].tolist())
                 grp_of_item = np.repeat(np.arange(len(gm)), [-(-c // ops.MAX_CHUNK) for c in counts[gm]])
-                quad, _, info = ops.score_groups(Y, means.contiguous(), self.Sigma, im, ia, io, ic, seg_ids=seg_list,
+                quad, _, info = ops.score_groups(Y, means.contiguous(), self._S("Sigma"), im, ia, io, ic, seg_ids=seg_list,
                                                  item_mean=inv[gm][grp_of_item].astype(np.int32))
                 ops.raise_on_info(info, "compute_sq_err_all")
             single = ~multi
             if single.any():  # member segments: each has its own Sigma_i and a single right-hand side
                 gs = np.nonzero(single)[0]
                 segs = torch.as_tensor(rep[gs], device=self.device)
-                q1, _, info1 = ops.score_each(Y[segs].contiguous(), means.contiguous(), self.Sigma, g_ci[gs].astype(np.int32),
+                q1, _, info1 = ops.score_each(Y[segs].contiguous(), means.contiguous(), self._S("Sigma"), g_ci[gs].astype(np.int32),
                                               inv[gs].astype(np.int32), adds[gs])
                 ops.raise_on_info(info1, "compute_sq_err_all")
                 quad[segs] = q1
@@ -245,9 +509,9 @@ class GPI_model:
         # general path (GPI_model.py:535-545): every segment against the state of ITS step, on its own grid
         pairs, col = np.unique(np.stack([ci_seg, fi_seg], 1), axis=0, return_inverse=True)
         col = col.reshape(-1)
-        means = ops.gemm_batched(self.C[torch.as_tensor(pairs[:, 0], device=self.device)],
-                                 self.f_star[torch.as_tensor(pairs[:, 1], device=self.device)]).reshape(-1, T)
-        Sig = self.Sigma[torch.as_tensor(pairs[:, 0], device=self.device)].contiguous()
+        means = ops.gemm_batched(self._S("C")[torch.as_tensor(pairs[:, 0], device=self.device)],
+                                 self._S("f_star")[torch.as_tensor(pairs[:, 1], device=self.device)]).reshape(-1, T)
+        Sig = self._S("Sigma")[torch.as_tensor(pairs[:, 0], device=self.device)].contiguous()
         plan = ops.PairsPlan(T, Ts, np.repeat(np.asarray(self.gp.kernel.params())[None], len(pairs), 0), device=self.device)
         plan.update(self.x_basis.reshape(-1).contiguous(), means.contiguous(), Sig)
         ops.raise_on_info(plan.info, "pred_dist")
@@ -274,12 +538,12 @@ class GPI_model:
             cur, prev, par, cov = [cur[only]], [prev[only]], [par[only]], [cov[only]]
         T = self.x_basis.shape[0]
         ix = lambda a: torch.as_tensor(a, device=self.device)  # noqa: E731
-        Gam = self.Gamma[ix(par)].clone()
+        Gam = self._S("Gamma")[ix(par)].clone()
         if only is None or only == 0:
             Gam[0] = Gam[0] * h_ini                                  # GPI_model.py:293
-        out, info = ops.lat_error(self.f_star_sm[ix(cur)].reshape(-1, T).contiguous(),
-                                  self.f_star_sm[ix(prev)].reshape(-1, T).contiguous(), self.A[ix(par)].contiguous(), Gam,
-                                  self.cov_f_sm[ix(cov)].contiguous())
+        out, info = ops.lat_error(self._S("f_star_sm")[ix(cur)].reshape(-1, T).contiguous(),
+                                  self._S("f_star_sm")[ix(prev)].reshape(-1, T).contiguous(), self._S("A")[ix(par)].contiguous(), Gam,
+                                  self._S("cov_f_sm")[ix(cov)].contiguous())
         ops.raise_on_info(info, "log_lat_error")
         return out - 0.5 * T * LOG2PI
 

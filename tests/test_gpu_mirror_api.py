@@ -146,3 +146,35 @@ def test_gemm_batched_shapes():
         assert np.allclose(ops.gemm_batched(dev(At), dev(B), transA=True).cpu().numpy(), A @ B, rtol=1e-12, atol=1e-12)
         Bt = np.ascontiguousarray(B.transpose(0, 2, 1))
         assert np.allclose(ops.gemm_batched(dev(A), dev(Bt), transB=True).cpu().numpy(), A @ B, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,members", [("t30", [2, 5, 6, 9, 12]), ("t45", [0, 1, 2, 3, 4, 7, 8, 11, 15, 16, 20]), ("t90", [0, 1, 3, 6])])
+def test_producer_full_pass_weighted_reproduces_reference_state(tag, members):
+    """the Kalman / RTS / MNIW recursion, driven exactly like the fixture generator drove the reference
+    (tests/golden/make_golden.py: build_model), must reproduce every per-step list and the scores computed from them."""
+    g = golden(f"state_{tag}.npz")
+    y = g["y"]
+    n, T = y.shape
+    assert list(g["st_indexes"]) == members
+    sigma, gamma = float(g["st_Sigma"][0][0, 0]), float(g["st_Gamma"][0][0, 0])
+    m = GPI_model(RBFWhiteKernel(300.0, 3.0, sigma * 1e-5), g["st_x_basis"][:, None], annealing=True, bayesian=True, free_deg_MNIV=5)
+    cond = m.GPR_dynamic(gamma, sigma)
+    m.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
+    m.fixed_theta = tuple(float(v) for v in g["st_theta"])          # what the (out-of-scope) gpytorch fit left behind
+    xs = np.repeat(g["st_x_basis"][None, :, None], n, axis=0)
+    resp = np.zeros(n)
+    resp[members] = 1.0
+    q, q_lat = m.full_pass_weighted(xs, y[:, :, None], resp)
+    assert m.indexes == members
+    tol = 1e-7
+    for name in ("f_star", "f_star_sm"):
+        got = torch.stack(getattr(m, name)).cpu().numpy()[:, :, 0]
+        assert np.allclose(got, g["st_" + name], rtol=tol, atol=tol * np.abs(g["st_" + name]).max()), name
+    for name in ("cov_f_sm", "A", "Gamma", "C", "Sigma"):
+        got = torch.stack(getattr(m, name)).cpu().numpy()
+        ref = g["st_" + name]
+        assert got.shape == ref.shape, name
+        assert np.allclose(got, ref, rtol=tol, atol=tol * np.abs(ref).max()), name
+    assert float(m.internal_params.n0) == float(g["st_n0"])
+    assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-6
+    assert rel_err(q_lat.cpu().numpy()[members], g["q_lat"][members]) < 1e-6
