@@ -316,6 +316,12 @@ def gen_offline(tag, rec, n, stride):
         out[f"m{m}_indexes"] = np.array(g.indexes, dtype=np.int64)
         out[f"m{m}_theta"] = kernel_theta(g.gp.kernel)
         out[f"m{m}_q_lat"] = npy(g.compute_q_lat_all(xt))
+        # what a fresh model needs to replay this cluster's final pass: initial LDS parameters and MNIW prior
+        out[f"m{m}_Gamma0"], out[f"m{m}_A0"], out[f"m{m}_C0"] = npy(g.Gamma[0]), npy(g.A[0]), npy(g.C[0])
+        out[f"m{m}_Gamma_last"], out[f"m{m}_A_last"] = npy(g.Gamma[-1]), npy(g.A[-1])
+        out[f"m{m}_f_star_sm_last"] = npy(g.f_star_sm[-1]).reshape(-1)
+        out[f"m{m}_n0"] = np.array(float(g.internal_params.n0))
+        out[f"m{m}_free_deg"] = np.array(float(g.free_deg_MNIV))
     out["q"] = np.stack(qs, axis=1)
     np.savez_compressed(os.path.join(OUT, f"offline_{tag}.npz"), **out)
     print(f"offline_{tag}: N={N} T={T} M={len(models)} counts={[len(g.indexes) for g in models]}")

@@ -178,3 +178,34 @@ def test_producer_full_pass_weighted_reproduces_reference_state(tag, members):
     assert float(m.internal_params.n0) == float(g["st_n0"])
     assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-6
     assert rel_err(q_lat.cpu().numpy()[members], g["q_lat"][members]) < 1e-6
+
+
+def test_replay_offline_trace_from_labels():
+    """labels -> recursion -> q matrix -> hard assignments, on the reference's own include_batch result (record 102,
+    60 beats, T = 45, 5 clusters): a fresh model per cluster is driven over the cluster's final members and must end
+    in the reference's state, score matrix and arg-max assignments."""
+    g = golden("offline_r102_t45.npz")
+    y, xb = g["y"], g["x_basis"]
+    N, M, T = y.shape[0], int(g["M"]), xb.size
+    xs = np.repeat(xb[None, :, None], N, axis=0)
+    q = np.zeros((N, M))
+    for mi in range(M):
+        members = [int(v) for v in g[f"m{mi}_indexes"]]
+        Sig0, Gam0 = g[f"m{mi}_Sigma"][0], g[f"m{mi}_Gamma0"]
+        mod = GPI_model(RBFWhiteKernel(300.0, 3.0, 1e-6), xb[:, None], annealing=True, bayesian=True,
+                        free_deg_MNIV=int(g[f"m{mi}_free_deg"]))
+        mod.initial_conditions(ini_A=g[f"m{mi}_A0"], ini_Gamma=Gam0, ini_C=g[f"m{mi}_C0"], ini_Sigma=Sig0)
+        mod.fixed_theta = tuple(float(v) for v in g[f"m{mi}_theta"])
+        resp = np.zeros(N)
+        resp[members] = 1.0
+        qm, qlat = mod.full_pass_weighted(xs, y[:, :, None], resp)
+        S = len(mod.f_star)
+        means = np.stack([(mod.C[min(i, len(mod.C) - 1)] @ mod.f_star[i]).cpu().numpy().reshape(-1) for i in range(S)])
+        assert np.allclose(means, g[f"m{mi}_means"], rtol=1e-6, atol=1e-6 * np.abs(g[f"m{mi}_means"]).max())
+        Sg = torch.stack(mod.Sigma).cpu().numpy()
+        assert np.allclose(Sg, g[f"m{mi}_Sigma"], rtol=1e-6, atol=1e-6 * np.abs(g[f"m{mi}_Sigma"]).max())
+        assert float(mod.internal_params.n0) == float(g[f"m{mi}_n0"])
+        assert rel_err(qlat.cpu().numpy()[members], g[f"m{mi}_q_lat"][members]) < 1e-5
+        q[:, mi] = qm.cpu().numpy()
+    assert rel_err(q, g["q"]) < 1e-5
+    assert np.array_equal(np.argmax(q, axis=1), np.argmax(g["q"], axis=1))
