@@ -44,7 +44,7 @@ class matrix_normal_inv_wishart:
     def set_scale(self, scale):
         self.scale = scale
 
-    def posterior(self, n_k, y1, y2, cov=None, cov_=None, cov_cross=None, sse_matrix=None, annealing=False):
+    def posterior(self, n_k, y1, y2, cov=None, cov_=None, cov_cross=None, sse_matrix=None, annealing=False, defer=None):
         """GPI_model.py:1300-1344 for n_k = 1, zero covariance corrections and no projection (the only call the
         one-step estimation makes on a shared grid, GPI_model.py:995-998,1034-1036)."""
         if n_k != 1 or sse_matrix is not None:
@@ -53,16 +53,16 @@ class matrix_normal_inv_wishart:
         dev = self.scale.device
         eye = torch.eye(T, dtype=f64, device=dev)
         new_n0 = self.n0 + n_k
-        jitter = 1e-2 * max(float(torch.mean(torch.diagonal(self.scale).abs())), np.finfo(np.float64).eps)
+        jitter = 1e-2 * torch.clamp_min(torch.mean(torch.diagonal(self.scale).abs()), np.finfo(np.float64).eps)
         m_r_cov = eye if self.m_r_cov is None else self.m_r_cov
-        _, info, Z = ops.potrf_batched(m_r_cov.contiguous(), 0.0, jitter, want_inv=True)       # :1313-1316
-        ops.raise_on_info(info, "MNIW.posterior")
+        _, info, Z = ops.potrf_batched((0.5 * (m_r_cov + m_r_cov.T) + jitter * eye).contiguous(), 0.0, 0.0, want_inv=True)   # :1313-1316
+        (defer.append(info) if defer is not None else ops.raise_on_info(info, "MNIW.posterior"))
         scale_inv = ops.gemm_batched(Z[0], Z[0], transA=True)
         y1, y2 = y1.reshape(T, 1), y2.reshape(T, 1)
         S__ = ops.gemm_batched(y2, y2, transB=True) + scale_inv                                 # :1321,1325
         S_ = ops.gemm_batched(y1, y2, transB=True) + ops.gemm_batched(self.m_mean.contiguous(), scale_inv)
         _, info, Zs = ops.potrf_batched(S__.contiguous(), 0.0, 1e-8, want_inv=True)             # :1329
-        ops.raise_on_info(info, "MNIW.posterior")
+        (defer.append(info) if defer is not None else ops.raise_on_info(info, "MNIW.posterior"))
         part_mean = ops.gemm_batched(ops.gemm_batched(S_.contiguous(), Zs[0], transB=True), Zs[0])   # S_ S__^{-1}
         new_m_mean = ((self.n0 - 2) * self.m_mean + part_mean) / (new_n0 - 2)                   # :1332-1336
         e = y1 - y2
@@ -105,6 +105,7 @@ class GPI_model:
         self.fixed_theta = None        # (c, ell, noise) taken by fit_kernel_params instead of the gpytorch fit
         self.noise_bounds = (1e-10, 1e10)
         self._stk = {}
+        self._pending = []
 
     # ------------------------------------------------------------------ state (a12)
     def cond_to_torch(self, x):
@@ -256,12 +257,22 @@ class GPI_model:
         self._stk = {}
         return self.x_basis, ini_cov
 
-    @staticmethod
-    def _spd_inv(S, what):
-        """S^{-1} of a symmetric positive-definite matrix through the Cholesky inverse: Z^T Z with Z = chol(S)^{-1}."""
+    def _spd_inv(self, S, what):
+        """S^{-1} of a symmetric positive-definite matrix through the Cholesky inverse: Z^T Z with Z = chol(S)^{-1}.
+        The LAPACK info is collected and checked once per pass (one host sync instead of one per solve)."""
         _, info, Z = ops.potrf_batched(S.contiguous(), 0.0, 0.0, want_inv=True)
-        ops.raise_on_info(info, what)
+        self._pending.append((what, info))
         return ops.gemm_batched(Z[0], Z[0], transA=True)
+
+    def _check_pending(self):
+        if self._pending:
+            infos = torch.cat([i for _, i in self._pending])
+            if bool(infos.any()):
+                bad = int(torch.nonzero(infos)[0, 0])
+                what = self._pending[bad][0]
+                self._pending = []
+                raise torch.linalg.LinAlgError(f"{what}: the input is not positive-definite")
+            self._pending = []
 
     def _posterior(self, mean_prior, cov_prior, y, A, Gamma, C, Sigma, first_step, h=1.0):
         """GPI.posterior (GPI.py:72-151) on the shared grid (x_warped == x_basis, K_cov = I)."""
@@ -337,10 +348,10 @@ class GPI_model:
         if full_data or h != 1.0:
             raise NotImplementedError("bayesian_new_params: only the one-step update with h = 1 is built")
         if 1 < self.N < self.estimation_limit or force:
-            try:
-                new_int = self.internal_params.posterior(1, self.f_star_sm[-1], self.f_star_sm[-2])
-                new_obs = self.observation_params.posterior(1, self.y_train[-1], self.f_star_sm[-1])
-            except torch.linalg.LinAlgError:            # GPI_model.py:1068-1071: keep the previous distributions
+            infos = []
+            new_int = self.internal_params.posterior(1, self.f_star_sm[-1], self.f_star_sm[-2], defer=infos)
+            new_obs = self.observation_params.posterior(1, self.y_train[-1], self.f_star_sm[-1], defer=infos)
+            if bool(torch.cat(infos).any()):             # GPI_model.py:1068-1071: keep the previous distributions
                 new_int, new_obs = self.internal_params, self.observation_params
         else:
             new_int, new_obs = self.internal_params, self.observation_params
@@ -394,6 +405,7 @@ class GPI_model:
                 self.bayesian_new_params(h)
         if dynamic:
             self.backwards()
+        self._check_pending()
         self._stk = {}
         return self.compute_sq_err_all(x_trains, y_trains), self.compute_q_lat_all(x_trains)
 

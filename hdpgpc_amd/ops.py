@@ -55,8 +55,8 @@ def potrf_batched(A, jitter_rel=1e-8, add_diag=0.0, want_inv=False, want_logdet=
     info = torch.zeros(b, dtype=torch.int32, device=A.device)
     Linv = torch.empty_like(L) if want_inv else None
     logdet = torch.empty(b, dtype=torch.float64, device=A.device) if want_logdet else None
-    _ffi.check(_ffi.lib.hgp_potrf_batched_f64(_ptr(L), T, b, jitter_rel, add_diag, _ptr(Linv), _ptr(logdet), _ptr(info),
-                                              _stream()), "potrf_batched")
+    _ffi.check(_ffi.lib.hgp_potrf_batched_f64(_ptr(L), T, b, float(jitter_rel), float(add_diag), _ptr(Linv), _ptr(logdet),
+                                              _ptr(info), _stream()), "potrf_batched")
     out = [L, info]
     if want_inv:
         out.append(Linv)
