@@ -50,6 +50,33 @@ def cpu_baseline(batch, budget_s=12.0):
                       f"of the same workload in {dt:.1f} s; NumPy/SciPy oracle, BLAS threads = all host cores"}
 
 
+def secondary_shared_grid(dev, ops, S=16384, T=90, reps=10):
+    """The reference's shared-grid member dataflow (records 100/102: T = 90, one Sigma_i per segment, one right-hand
+    side each; SURVEY.md 8d 'secondary'): hgp_score_each_f64, HBM-bound, 8 T^2 + 16 T + 8 algorithmic bytes per eval.
+    Measured outside the timed region of the headline metric."""
+    rng = np.random.default_rng(1)
+    Q = rng.normal(size=(64, T, T))
+    A = Q @ Q.transpose(0, 2, 1) / T + np.eye(T)
+    Sig = torch.as_tensor(np.tile(A, (S // 64, 1, 1)), dtype=torch.float64, device=dev)
+    Y = torch.as_tensor(rng.normal(size=(S, T)), dtype=torch.float64, device=dev)
+    mean = torch.as_tensor(rng.normal(size=(S, T)), dtype=torch.float64, device=dev)
+    sm = torch.arange(S, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        ops.score_each(Y, mean, Sig, sm)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.score_each(Y, mean, Sig, sm)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    byts = S * (8.0 * T * T + 16 * T + 8)
+    gbs = byts / (ms * 1e-3) / 1e9
+    return {"workload": f"shared-grid member path: {S} segments, one Sigma_i each, T={T} (k_wave_score1)",
+            "value": S / (ms * 1e-3), "unit": "evals/s", "kernel_ms": ms,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,8 +173,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "k_pairs<8>", "kernel_ms": kern_ms,
-                         "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T_LEN)},
+                         "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T_LEN),
+                         # what the kernel actually issues (band-skipped): 1548 v_mfma_f64_16x16x4 of 2048 FLOP per pair
+                         "executed_mfma_tflops": N_SEG * K_CL * 1548 * 2048 / (kern_ms * 1e-3) / 1e12},
         }
+        if world == 1:
+            res["secondary"] = secondary_shared_grid(dev, ops)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(batch)
         print(json.dumps(res), flush=True)
