@@ -106,6 +106,7 @@ class GPI_model:
         self.noise_bounds = (1e-10, 1e10)
         self._stk = {}
         self._pending = []
+        self._sym_cache = {}
 
     # ------------------------------------------------------------------ state (a12)
     def cond_to_torch(self, x):
@@ -513,8 +514,13 @@ class GPI_model:
             if single.any():  # member segments: each has its own Sigma_i and a single right-hand side
                 gs = np.nonzero(single)[0]
                 segs = torch.as_tensor(rep[gs], device=self.device)
-                q1, _, info1 = ops.score_each(Y[segs].contiguous(), means.contiguous(), self._S("Sigma"), g_ci[gs].astype(np.int32),
-                                              inv[gs].astype(np.int32), adds[gs])
+                Sst = self._S("Sigma")
+                sym = self._sym_cache.get(id(Sst))
+                if sym is None:      # one device check per stacked tensor: exactly symmetric stacks take the half-traffic path
+                    sym = bool(torch.equal(Sst, Sst.transpose(1, 2)))
+                    self._sym_cache = {id(Sst): sym}
+                q1, _, info1 = ops.score_each(Y[segs].contiguous(), means.contiguous(), Sst, g_ci[gs].astype(np.int32),
+                                              inv[gs].astype(np.int32), adds[gs], symmetric=sym)
                 ops.raise_on_info(info1, "compute_sq_err_all")
                 quad[segs] = q1
             return -0.5 * quad - 0.5 * T * LOG2PI

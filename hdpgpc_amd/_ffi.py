@@ -27,7 +27,7 @@ def _load():
         "hgp_gram_rbf_f64": (i32, [vp, i32, vp, i32, f64, f64, f64, vp, vp]),
         "hgp_potrf_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, vp]),
         "hgp_score_groups_f64": (i32, [vp, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, f64, vp, vp, vp, vp]),
-        "hgp_score_each_f64": (i32, [vp, i32, vp, i64, vp, i64, i32, vp, vp, vp, i32, f64, vp, vp, vp, vp]),
+        "hgp_score_each_f64": (i32, [vp, i32, vp, i64, vp, i64, i32, vp, vp, vp, i32, f64, i32, vp, vp, vp, vp]),
         "hgp_pairs_plan_device_bytes": (sz, [i32, i32, i32]),
         "hgp_pairs_plan_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, ctypes.POINTER(f64), vp, sz]),
         "hgp_pairs_plan_destroy": (None, [vp]),

@@ -247,6 +247,7 @@ struct EachArgs {
   double* out_quad;
   double* out_logdet;
   int32_t* out_info;
+  int symmetric;             // caller guarantees Sigma == Sigma^T bit for bit: read the upper triangle only
 };
 
 template <int NB>
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 6) ? 2 : 1) void k_wave_score1(E
   for (int i = lane; i < 16 * NB; i += 64) dv[i] = (i < T) ? yr[i] - (mu ? mu[i] : 0.0) : 0.0;
   d4 U[NB * (NB + 1) / 2];
   d4 Rnone[NB];
-  load_sym_upper<NB>(U, S, T, T, lane);
+  if (a.symmetric) load_upper_only<NB>(U, S, T, T, lane);
+  else load_sym_upper<NB>(U, S, T, T, lane);
   {
     double sh = a.seg_add ? a.seg_add[seg] : 0.0;
     if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(diag_abs_mean<NB>(U, T, lane, sh), F64_EPS);
@@ -1631,12 +1633,13 @@ int hgp_debug_stamps(unsigned long long* out8_host) {
 
 int hgp_score_each_f64(const double* Y, int ldy, const double* mean, long mean_stride, const double* Sigma,
                        long sigma_stride, int T, const int32_t* seg_mat, const int32_t* seg_mean, const double* seg_add,
-                       int n, double jitter_rel, double* out_quad, double* out_logdet, int32_t* out_info, void* stream) {
+                       int n, double jitter_rel, int symmetric, double* out_quad, double* out_logdet, int32_t* out_info,
+                       void* stream) {
   if (n == 0) return 0;
   if (!Y || !Sigma || !seg_mat || !out_quad || T <= 0 || ldy < T || n < 0) return -1;
   if (T > HGP_MAX_T_WAVE) return -2;   // larger T: hgp_score_groups_f64 with one segment per item
   EachArgs a{Y, ldy, mean, mean_stride, Sigma, sigma_stride, T, n, seg_mat, seg_mean, seg_add, jitter_rel, out_quad, out_logdet,
-             out_info};
+             out_info, symmetric};
   dim3 grid((n + WAVES - 1) / WAVES), blk(64 * WAVES);
   hipStream_t st = (hipStream_t)stream;
   switch (nb_for(T)) {

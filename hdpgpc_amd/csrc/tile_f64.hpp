@@ -338,6 +338,31 @@ __device__ __forceinline__ void load_sym_upper(d4 (&U)[NB * (NB + 1) / 2], const
   }
 }
 
+// upper tiles of a matrix the caller guarantees to be symmetric: only the tiles I <= J are read (about half the
+// bytes), every access coalesced (no transposed partner read)
+template <int NB>
+__device__ __forceinline__ void load_upper_only(d4 (&U)[NB * (NB + 1) / 2], const double* __restrict__ A, int ld, int n,
+                                                int lane_in) {
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+#pragma unroll
+    for (int J = I; J < NB; ++J) {
+      const int lane = launder(lane_in);
+      const int g = lane >> 4, c = lane & 15;
+      d4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = 16 * I + g + 4 * r, j = 16 * J + c;
+        double x = 0.0;
+        if (i < n && j < n) x = A[(size_t)i * ld + j];
+        else if (i == j) x = 1.0;
+        v[r] = x;
+      }
+      U[tix(I, J, NB)] = v;
+    }
+  }
+}
+
 // add `shift` to the diagonal entries i < n (padded rows keep their 1)
 template <int NB>
 __device__ __forceinline__ void add_diag(d4 (&U)[NB * (NB + 1) / 2], double shift, int n, int lane_in) {

@@ -117,8 +117,10 @@ def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids
     return quad, logdet, info
 
 
-def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=1e-8, want_logdet=False, want_info=True):
-    """a6 for member segments: segment i against its own state.  Y [n,T]; mean [S,T]; Sigma [S,T,T]; seg_* [n]."""
+def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=1e-8, want_logdet=False, want_info=True,
+               symmetric=False):
+    """a6 for member segments: segment i against its own state.  Y [n,T]; mean [S,T]; Sigma [S,T,T]; seg_* [n].
+    symmetric=True promises Sigma == Sigma^T exactly (upper triangle read only)."""
     Y = _dev64(Y, "Y")
     Sigma = _dev64(Sigma, "Sigma")
     dev = Y.device
@@ -136,7 +138,8 @@ def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=
     logdet = torch.zeros(n, dtype=torch.float64, device=dev) if want_logdet else None
     info = torch.zeros(n, dtype=torch.int32, device=dev) if want_info else None
     _ffi.check(_ffi.lib.hgp_score_each_f64(_ptr(Y), T, _ptr(mean), T, _ptr(Sigma), T * T, T, _ptr(sm), _ptr(sme), _ptr(sa), n,
-                                           jitter_rel, _ptr(quad), _ptr(logdet), _ptr(info), _stream()), "score_each")
+                                           jitter_rel, int(bool(symmetric)), _ptr(quad), _ptr(logdet), _ptr(info), _stream()),
+               "score_each")
     return quad, logdet, info
 
 

@@ -72,10 +72,13 @@ int hgp_score_groups_f64(const double* Y, int ldy, const double* mean, long mean
  * (GPI_model.py:508-531): one Sigma_i, one right-hand side.  Same arithmetic as hgp_score_groups_f64 with one
  * segment per item, on a leaner kernel (T <= 128):
  *   cov_i = 0.5 (S + S^T) + seg_add[i] I + jitter_rel max(mean|diag|, eps) I,  S = Sigma + seg_mat[i] * sigma_stride
- *   out_quad[i] = (Y[i] - m)^T cov_i^{-1} (Y[i] - m),   m = mean + (seg_mean ? seg_mean[i] : seg_mat[i]) * mean_stride */
+ *   out_quad[i] = (Y[i] - m)^T cov_i^{-1} (Y[i] - m),   m = mean + (seg_mean ? seg_mean[i] : seg_mat[i]) * mean_stride
+ * symmetric != 0: the caller guarantees every Sigma to equal its transpose bit for bit (true for the MNIW scale
+ * recursion, GPI_model.py:1332-1336); only the upper triangle is then read (about half the HBM bytes). */
 int hgp_score_each_f64(const double* Y, int ldy, const double* mean, long mean_stride, const double* Sigma,
                        long sigma_stride, int T, const int32_t* seg_mat, const int32_t* seg_mean, const double* seg_add,
-                       int n, double jitter_rel, double* out_quad, double* out_logdet, int32_t* out_info, void* stream);
+                       int n, double jitter_rel, int symmetric, double* out_quad, double* out_logdet, int32_t* out_info,
+                       void* stream);
 
 /* a2 + a5 - the per-(segment, cluster) general path: IterativeGaussianProcess.pred_dist (GPI.py:457-503)
  * followed by the score of GPI_model.log_sq_error (GPI_model.py:250-286), for an N x K batch.

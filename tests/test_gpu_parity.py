@@ -291,3 +291,17 @@ def test_score_each_own_state_per_segment(T):
         q_ref, ld_ref = orc.quad_logdet(Y[i] - mean[sme[i]], Sig[sm[i]] + add[i] * np.eye(T))
         assert abs(float(quad[i]) - q_ref) <= RT_WAVE * abs(q_ref)
         assert abs(float(logdet[i]) - ld_ref) <= 1e-10 * max(1.0, abs(ld_ref))
+
+
+def test_score_each_symmetric_fast_path_matches():
+    rng = np.random.default_rng(77)
+    n, T = 50, 90
+    Q = rng.normal(size=(n, T, T))
+    Sig = Q @ Q.transpose(0, 2, 1) / T + np.eye(T)
+    Sig = 0.5 * (Sig + Sig.transpose(0, 2, 1))
+    Y, mean = rng.normal(size=(n, T)), rng.normal(size=(n, T))
+    sm = np.arange(n, dtype=np.int32)
+    q0, ld0, _ = ops.score_each(dev(Y), dev(mean), dev(Sig), sm, want_logdet=True)
+    q1, ld1, i1 = ops.score_each(dev(Y), dev(mean), dev(Sig), sm, want_logdet=True, symmetric=True)
+    assert int(i1.abs().max()) == 0
+    assert torch.equal(q0, q1) and torch.equal(ld0, ld1)     # same arithmetic: 0.5 (a + a) == a exactly

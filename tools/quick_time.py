@@ -45,3 +45,6 @@ for (S,T) in [(4096,128),(4096,90),(4096,64),(16384,90)]:
     sm=torch.arange(S,dtype=torch.int32,device="cuda")
     t=timeit(lambda: ops.score_each(Y,mean,Sig,sm))
     print(f"score_each   S={S} T={T}: {t*1e3:.3f} ms -> {S/t:.3e} evals/s, {S*T*T*8/t/1e9:.1f} GB/s", flush=True)
+    Ss=(0.5*(Sig+Sig.transpose(1,2))).contiguous()
+    t=timeit(lambda: ops.score_each(Y,mean,Ss,sm,symmetric=True))
+    print(f"score_each(sym) S={S} T={T}: {t*1e3:.3f} ms -> {S/t:.3e} evals/s, {S*T*T*8/t/1e9:.1f} GB/s (algorithmic bytes)", flush=True)
