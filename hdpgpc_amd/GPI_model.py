@@ -55,13 +55,13 @@ class matrix_normal_inv_wishart:
         new_n0 = self.n0 + n_k
         jitter = 1e-2 * torch.clamp_min(torch.mean(torch.diagonal(self.scale).abs()), np.finfo(np.float64).eps)
         m_r_cov = eye if self.m_r_cov is None else self.m_r_cov
-        _, info, Z = ops.potrf_batched((0.5 * (m_r_cov + m_r_cov.T) + jitter * eye).contiguous(), 0.0, 0.0, want_inv=True)   # :1313-1316
+        Z, info = ops.chol_inverse((0.5 * (m_r_cov + m_r_cov.T) + jitter * eye).contiguous())   # :1313-1316
         (defer.append(info) if defer is not None else ops.raise_on_info(info, "MNIW.posterior"))
         scale_inv = ops.gemm_batched(Z[0], Z[0], transA=True)
         y1, y2 = y1.reshape(T, 1), y2.reshape(T, 1)
         S__ = ops.gemm_batched(y2, y2, transB=True) + scale_inv                                 # :1321,1325
         S_ = ops.gemm_batched(y1, y2, transB=True) + ops.gemm_batched(self.m_mean.contiguous(), scale_inv)
-        _, info, Zs = ops.potrf_batched(S__.contiguous(), 0.0, 1e-8, want_inv=True)             # :1329
+        Zs, info = ops.chol_inverse(S__.contiguous(), 0.0, 1e-8)                                # :1329
         (defer.append(info) if defer is not None else ops.raise_on_info(info, "MNIW.posterior"))
         part_mean = ops.gemm_batched(ops.gemm_batched(S_.contiguous(), Zs[0], transB=True), Zs[0])   # S_ S__^{-1}
         new_m_mean = ((self.n0 - 2) * self.m_mean + part_mean) / (new_n0 - 2)                   # :1332-1336
@@ -261,7 +261,7 @@ class GPI_model:
     def _spd_inv(self, S, what):
         """S^{-1} of a symmetric positive-definite matrix through the Cholesky inverse: Z^T Z with Z = chol(S)^{-1}.
         The LAPACK info is collected and checked once per pass (one host sync instead of one per solve)."""
-        _, info, Z = ops.potrf_batched(S.contiguous(), 0.0, 0.0, want_inv=True)
+        Z, info = ops.chol_inverse(S.contiguous())
         self._pending.append((what, info))
         return ops.gemm_batched(Z[0], Z[0], transA=True)
 
@@ -389,8 +389,165 @@ class GPI_model:
             self.cov_f_sm[i + 1] = covs[i]
         self._stk = {}
 
-    def full_pass_weighted(self, x_trains, y_trains, resp, q=None, q_lat=None, snr=None):
-        """GPI_model.py:377-406: filter / smooth / re-estimate over the members (resp > 0.99), then score everything."""
+    # ---- the same recursion as capture-safe, buffer-based steps replayed as hipGraphs ----------------------------
+    # The eager methods above issue ~90 launches and one host sync per member: launch-bound.  For a run of members
+    # (dynamic model, shared grid, h = 1, N >= 2) the step is restated on pre-allocated stacks with device-side
+    # indices/counters and no host synchronisation, captured once with torch.cuda.CUDAGraph (hipGraph) and replayed per
+    # member; the RTS backward pass likewise.  Same arithmetic, same order.
+    def _chain_alloc(self, n_more):
+        T = self.x_basis.shape[0]
+        L = len(self.f_star)
+        dev = self.device
+
+        def stack(lst, shape):
+            buf = torch.zeros((L + n_more,) + shape, dtype=f64, device=dev)
+            buf[:L] = torch.stack(lst)
+            return buf
+
+        ch = {"F": stack(self.f_star, (T, 1)), "Fsm": stack(self.f_star_sm, (T, 1)), "P": stack(self.cov_f, (T, T)),
+              "Psm": stack(self.cov_f_sm, (T, T)), "A": stack(self.A, (T, T)), "G": stack(self.Gamma, (T, T)),
+              "C": stack(self.C, (T, T)), "S": stack(self.Sigma, (T, T))}
+        ch["pos"] = torch.tensor([L - 1], dtype=torch.int64, device=dev)
+        ch["Nf"] = torch.tensor(float(self.N), dtype=f64, device=dev)
+        ch["n0"] = torch.tensor(float(self.internal_params.n0), dtype=f64, device=dev)
+        eye = self._eye()
+        for tag, mn in (("i", self.internal_params), ("o", self.observation_params)):
+            ch["m" + tag] = mn.m_mean.clone()
+            ch["R" + tag] = (eye if mn.m_r_cov is None else mn.m_r_cov).clone()
+            ch["s" + tag] = mn.scale.clone()
+        ch["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        return ch
+
+    @staticmethod
+    def _mniw_post_dev2(means, Rs, scales, n0, y1s, y2s, eye):
+        """Two matrix_normal_inv_wishart.posterior updates (internal, observation) as ONE batch of 2: every operand is
+        [2,T,T] / [2,T,1]; n0 is a device scalar.  Returns (means', R', scales', info[2])."""
+        mm = ops.gemm_batched
+        jit = 1e-2 * torch.clamp_min(torch.mean(torch.diagonal(scales, dim1=1, dim2=2).abs(), dim=1), np.finfo(np.float64).eps)
+        Z, i1 = ops.chol_inverse((0.5 * (Rs + Rs.transpose(1, 2)) + jit.reshape(2, 1, 1) * eye).contiguous())
+        scale_inv = mm(Z, Z, transA=True)
+        S__ = mm(y2s, y2s, transB=True) + scale_inv
+        S_ = mm(y1s, y2s, transB=True) + mm(means.contiguous(), scale_inv)
+        Zs, i2 = ops.chol_inverse(S__.contiguous(), 0.0, 1e-8)
+        part = mm(mm(S_.contiguous(), Zs, transB=True), Zs)
+        new_means = ((n0 - 2.0) * means + part) / (n0 - 1.0)
+        e = y1s - y2s
+        new_scales = ((n0 - 2.0) * scales + mm(e, e, transB=True)) / (n0 - 1.0)
+        return new_means, S__, new_scales, i1 + i2
+
+    def _chain_step(self, ch, y):
+        """One member (N >= 2 after it): include_sample + backwards_pair + bayesian_new_params on the stacks."""
+        mm = ops.gemm_batched
+        eye = self._eye()
+        pos = ch["pos"]
+        nxt = pos + 1
+        sel = lambda k: ch[k].index_select(0, pos)[0]     # noqa: E731
+        A, G, C, S = sel("A"), sel("G"), sel("C"), sel("S")
+        f_post, c_post = self._posterior(sel("Fsm"), sel("Psm"), y, A, G, C, S, False)
+        m0, c0 = sel("F"), sel("P")                        # filtered values of the previous step
+        for k, v in (("F", f_post), ("Fsm", f_post), ("P", c_post), ("Psm", c_post)):
+            ch[k].index_copy_(0, nxt, v.unsqueeze(0))
+        # backwards_pair on the last two filtered states
+        P = mm(mm(A, c0), A, transB=True) + G
+        J = mm(mm(c0, A, transB=True), self._spd_inv(0.5 * (P + P.T), "backwards_pair"))
+        f_sm_prev = m0 + mm(J, f_post - mm(A, m0))
+        ch["Fsm"].index_copy_(0, pos, f_sm_prev.unsqueeze(0))
+        ch["Psm"].index_copy_(0, pos, (c0 + mm(mm(J, c_post - P), J, transB=True)).unsqueeze(0))
+        # bayesian_new_params (one-step MNIW update; on a failed factorisation the previous distributions are kept)
+        n0 = ch["n0"]
+        nm, nR, ns, binfo = self._mniw_post_dev2(torch.stack((ch["mi"], ch["mo"])), torch.stack((ch["Ri"], ch["Ro"])),
+                                                 torch.stack((ch["si"], ch["so"])), n0, torch.stack((f_post, y)),
+                                                 torch.stack((f_sm_prev, f_post)), eye)
+        bad = (binfo.sum() != 0).reshape(1)
+        ch["bad"] += bad.to(torch.int32)
+        for k, v in (("mi", nm[0]), ("Ri", nR[0]), ("si", ns[0]), ("mo", nm[1]), ("Ro", nR[1]), ("so", ns[1])):
+            ch[k].copy_(torch.where(bad, ch[k], v))
+        n0_new = torch.where(bad[0], n0, n0 + 1.0)
+        Nf = ch["Nf"] + 1.0
+        scl = n0_new / (n0_new - 2.0)
+        ch["A"].index_copy_(0, nxt, ch["mi"].unsqueeze(0))
+        ch["C"].index_copy_(0, nxt, ch["mo"].unsqueeze(0))
+        ann = 1.0 / (Nf * Nf) if self.annealing else 0.0
+        ch["G"].index_copy_(0, nxt, (ch["si"] * scl + ch["G"][0] * ann).unsqueeze(0))
+        ch["S"].index_copy_(0, nxt, (ch["so"] * scl + ch["S"][0] * ann).unsqueeze(0))
+        ch["n0"].copy_(n0_new)
+        ch["Nf"].copy_(Nf)
+        ch["pos"].add_(1)
+
+    def _chain_commit(self, ch, members, x_trains, y_trains):
+        L = int(ch["pos"][0]) + 1
+        unb = lambda k: list(ch[k][:L].unbind(0))          # noqa: E731
+        self.f_star, self.f_star_sm, self.cov_f, self.cov_f_sm = unb("F"), unb("Fsm"), unb("P"), unb("Psm")
+        self.A, self.Gamma, self.C, self.Sigma = unb("A"), unb("G"), unb("C"), unb("S")
+        n0 = float(ch["n0"])
+        self.internal_params = matrix_normal_inv_wishart(ch["mi"], ch["Ri"], n0, ch["si"])
+        self.observation_params = matrix_normal_inv_wishart(ch["mo"], ch["Ro"], n0, ch["so"])
+        for idx in members:
+            self.indexes.append(int(idx))
+            self.x_train.append(x_trains[idx])
+            self.y_train.append(y_trains[idx].reshape(-1, 1))
+        self.N += len(members)
+        self._stk = {}
+
+    def _run_graphed(self, fn, n_iter):
+        """Capture fn() once on a side stream and replay it n_iter times (falls back to eager calls if capture fails)."""
+        if n_iter <= 0:
+            return
+        self._check_pending()
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()                                        # warm-up iteration (counts as the first one)
+            torch.cuda.current_stream().wait_stream(side)
+            n_iter -= 1
+            if n_iter == 0:
+                return
+            graph = torch.cuda.CUDAGraph()
+            keep = self._pending
+            with torch.cuda.graph(graph):
+                fn()
+            self._pending = keep + self._pending            # info tensors written by every replay
+            for _ in range(n_iter):
+                graph.replay()
+            self._graph_keepalive = graph
+        except RuntimeError:
+            for _ in range(n_iter):
+                fn()
+
+    def _backwards_graphed(self):
+        """GPI_model.backwards (full RTS) with the step captured once: index t runs down on the device."""
+        mm = ops.gemm_batched
+        L = len(self.f_star)
+        if L - 1 < 2:
+            return self.backwards()
+        M = torch.stack(self.f_star[1:]).contiguous()
+        Cv = torch.stack(self.cov_f[1:]).contiguous()
+        A = torch.stack(self.A[1:]).contiguous()
+        G = torch.stack(self.Gamma[1:]).contiguous()
+        nA = A.shape[0]
+        t = torch.tensor([M.shape[0] - 2], dtype=torch.int64, device=self.device)
+
+        def step():
+            ta = torch.clamp_max(t, nA - 1)
+            At, Gt = A.index_select(0, ta)[0], G.index_select(0, ta)[0]
+            mt, ct = M.index_select(0, t)[0], Cv.index_select(0, t)[0]
+            mn, cn = M.index_select(0, t + 1)[0], Cv.index_select(0, t + 1)[0]
+            P = mm(mm(At, ct), At, transB=True) + Gt
+            J = mm(mm(ct, At, transB=True), self._spd_inv(0.5 * (P + P.T), "backwards"))
+            M.index_copy_(0, t, (mt + mm(J, mn - mm(At, mt))).unsqueeze(0))
+            Cv.index_copy_(0, t, (ct + mm(mm(J, cn - P), J, transB=True)).unsqueeze(0))
+            t.sub_(1)
+
+        self._run_graphed(step, M.shape[0] - 1)
+        for i in range(M.shape[0]):
+            self.f_star_sm[i + 1] = M[i]
+            self.cov_f_sm[i + 1] = Cv[i]
+        self._stk = {}
+
+    def full_pass_weighted(self, x_trains, y_trains, resp, q=None, q_lat=None, snr=None, use_graphs=True):
+        """GPI_model.py:377-406: filter / smooth / re-estimate over the members (resp > 0.99), then score everything.
+        With use_graphs (default) members beyond the first are processed by hipGraph replays of the captured step."""
         x_trains = self.cond_to_torch(x_trains)
         y_trains = self.cond_to_torch(y_trains)
         resp = torch.as_tensor(resp)
@@ -398,14 +555,39 @@ class GPI_model:
         active = torch.nonzero(resp > 0.99, as_tuple=False).reshape(-1).tolist()
         if len(active) == 0:
             return q, q_lat
-        for index in active:
-            h = float(resp[index])
-            self.include_weighted_sample(index, x_trains[index], x_trains[index], y_trains[index], h)
+        hs = [float(resp[i]) for i in active]
+        X2 = x_trains[..., 0] if x_trains.ndim == 3 else x_trains
+        graphable = (use_graphs and dynamic and all(h == 1.0 for h in hs) and len(active) >= 4 and
+                     self.estimation_limit == np.inf and
+                     bool(torch.equal(X2[active], self.x_basis.reshape(1, -1).expand(len(active), -1))))
+        if graphable:
+            head = 1 if self.N == 0 else 0                  # the first member of a fresh model takes the eager path
+            for index in active[:head]:
+                self.include_weighted_sample(index, x_trains[index], x_trains[index], y_trains[index], 1.0)
+                self.backwards_pair(1.0)
+                self.bayesian_new_params(1.0)
+            rest = active[head:]
+            ch = self._chain_alloc(len(rest))
+            Yr = (y_trains[rest][..., 0] if y_trains.ndim == 3 else y_trains[rest]).reshape(len(rest), -1, 1).contiguous()
+            k = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+            def step():
+                self._chain_step(ch, Yr.index_select(0, k)[0])
+                k.add_(1)
+
+            self._run_graphed(step, len(rest))
+            self._chain_commit(ch, rest, x_trains, y_trains)
+            if int(ch["bad"][0]) != 0 and self.verbose:
+                print("Alg error matrix ill conditioned.")     # GPI_model.py:1069
+            self._backwards_graphed()
+        else:
+            for index, h in zip(active, hs):
+                self.include_weighted_sample(index, x_trains[index], x_trains[index], y_trains[index], h)
+                if dynamic:
+                    self.backwards_pair(h)
+                    self.bayesian_new_params(h)
             if dynamic:
-                self.backwards_pair(h)
-                self.bayesian_new_params(h)
-        if dynamic:
-            self.backwards()
+                self.backwards()
         self._check_pending()
         self._stk = {}
         return self.compute_sq_err_all(x_trains, y_trains), self.compute_q_lat_all(x_trains)

@@ -499,14 +499,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   double* C = a.C + (size_t)b1 * a.sC + (size_t)b2 * a.sC2;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
   const int row = 16 * ti + c, col = 16 * tj + c;
-  for (int kk = 0; kk < (a.Kd + 3) / 4; ++kk) {
-    const int k = 4 * kk + g;
-    double av = 0.0, bv = 0.0;
-    if (k < a.Kd) {
-      if (row < a.M) av = a.tA ? A[(size_t)k * a.lda + row] : A[(size_t)row * a.lda + k];
-      if (col < a.N) bv = a.tB ? B[(size_t)col * a.ldb + k] : B[(size_t)k * a.ldb + col];
+  const int nk = (a.Kd + 3) / 4;
+  for (int k0 = 0; k0 < nk; k0 += 8) {   // 8 k-steps per trip: their 16 operand loads are issued before the first MFMA
+    double av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = 4 * (k0 + u) + g;
+      av[u] = 0.0;
+      bv[u] = 0.0;
+      if (k < a.Kd) {
+        if (row < a.M) av[u] = a.tA ? A[(size_t)k * a.lda + row] : A[(size_t)row * a.lda + k];
+        if (col < a.N) bv[u] = a.tB ? B[(size_t)col * a.ldb + k] : B[(size_t)k * a.ldb + col];
+      }
     }
-    acc = mfma(av, bv, acc);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = mfma(av[u], bv[u], acc);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1647,6 +1654,23 @@ int hgp_score_each_f64(const double* Y, int ldy, const double* mean, long mean_s
     case 4: hipLaunchKernelGGL(k_wave_score1<4>, grid, blk, 0, st, a); break;
     case 6: hipLaunchKernelGGL(k_wave_score1<6>, grid, blk, 0, st, a); break;
     default: hipLaunchKernelGGL(k_wave_score1<8>, grid, blk, 0, st, a); break;
+  }
+  return launch_status();
+}
+
+int hgp_chol_inverse_batched_f64(const double* A, int T, int b, double jitter_rel, double add_diag, double* Linv,
+                                 int32_t* info, void* stream) {
+  if (b == 0) return 0;
+  if (!A || !Linv || T <= 0 || b < 0) return -1;
+  if (T > HGP_MAX_T_WAVE) return -2;
+  PotrfArgs a{const_cast<double*>(A), T, b, jitter_rel, add_diag, Linv, nullptr, info};
+  a.inv_info = 1;
+  hipStream_t st = (hipStream_t)stream;
+  switch (nb_for(T)) {
+    case 2: launch_wave_inv<2>(a, st); break;
+    case 4: launch_wave_inv<4>(a, st); break;
+    case 6: launch_wave_inv<6>(a, st); break;
+    default: launch_wave_inv<8>(a, st); break;
   }
   return launch_status();
 }
