@@ -77,16 +77,14 @@ __device__ __forceinline__ double xrow_sum(double v) {
   return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
-// 1/sqrt(a) for a > 0 (normal range): v_rsq_f64 seed (about 23 good bits) + two Newton steps; within
-// an ulp or two of 1.0/sqrt(a).  LAPACK's dpotf2 also scales the column by a rounded reciprocal.
+// 1/sqrt(a) for a > 0 (normal range): v_rsq_f64 seed (measured 5.2e-8 relative, tools/probe_rsq.hip) + ONE third-order
+// step  y (1 + e (1 + 1.5 e)),  e = 0.5 - 0.5 a y^2  -> 2.6e-16, the same as two Newton steps with a dependency
+// chain two operations shorter (the pivot chain is the critical path of every factorisation here).
+// LAPACK's dpotf2 also scales the column by a rounded reciprocal.
 __device__ __forceinline__ double rsqrt_nr(double a) {
-  double y = __builtin_amdgcn_rsq(a);
-  const double h = 0.5 * a;
-  double e = fma(-(h * y), y, 0.5);
-  y = fma(y, e, y);
-  e = fma(-(h * y), y, 0.5);
-  y = fma(y, e, y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(a);
+  const double e = fma(-(0.5 * a * y), y, 0.5);
+  return fma(y * e, fma(1.5, e, 1.0), y);
 }
 
 // log-determinant accumulator (product of pivots kept as mantissa * 2^ex) + LAPACK-style info
