@@ -149,11 +149,13 @@ __device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAc
     pa.mant *= piv;                                            // the outputs with NaN, info says where
     if ((k & 3) == 3) pa.renorm();       // four pivots between renormalisations: no over/underflow for |log2 piv| < 250
     v[k] *= rsqrt_nr(piv);
+    // all broadcasts of the step first (distinct SGPR pairs), then the FMAs: the VALU->SGPR->VALU hazard of a
+    // readlane that feeds the very next instruction is paid once per step instead of once per element
+    double sb[16];
 #pragma unroll
-    for (int kp = k + 1; kp < 16; ++kp) {
-      const double s = lane_bcast(v[k], kp);                   // U[k][k'] (= L[k'][k])
-      v[kp] = fma(-s, v[k], v[kp]);
-    }
+    for (int kp = k + 1; kp < 16; ++kp) sb[kp] = lane_bcast(v[k], kp);   // U[k][k'] (= L[k'][k])
+#pragma unroll
+    for (int kp = k + 1; kp < 16; ++kp) v[kp] = fma(-sb[kp], v[k], v[kp]);
   }
   if (Lout != nullptr && lane < 16 && lane < nvalid) {
 #pragma unroll
