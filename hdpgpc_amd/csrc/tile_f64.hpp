@@ -56,6 +56,11 @@ __device__ __forceinline__ int launder(int x) {
   return x;
 }
 
+__device__ __forceinline__ double launder_f64(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -115,17 +120,106 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 
 // ---------------------------------------------------------------------------------------------
 // diag16: Cholesky of one 16x16 diagonal block AND the inverse of its factor, by one wave.
-//   in : X  (acc layout; only the upper triangle i <= j is read)
+//   in : X  (acc layout, the full symmetric block: the lower triangle must hold finite numbers)
 //   out: returns W = L^{-1} (L = U^T lower) in A-operand layout, w[s] = W[c][4s+g];
-//        if Lout != nullptr lane j < 16 writes row j of L (zeros above the diagonal).
-// Lanes 0..15 hold column j of U; lanes 16..31 run the forward substitution L Z = I on column j of Z with the SAME
-// instruction stream: both need the scalars U[k][k'] (= L[k'][k]), broadcast from lane k' with v_readlane.
-// Right-looking, row by row: once row k is final every later row takes  v[k'] -= U[k][k'] v[k]  independently.
-// Measured alternatives (tools/stamps.py, gfx950): this form 7.6k cycles per block; a v_mov_b64_dpp row_newbcast
-// variant with U and Z in the same lanes 6.4k but +32 VGPR, which spills the NB = 8 kernels (net loss, reverted);
-// v_readlane itself costs ~25 cycles (tools/probe_coexec.hip).
+//        if Lout != nullptr the wave writes L (zeros above the diagonal) for rows/cols < nvalid.
+// Blocked 4 x 4 inside the tile so that the O(16^3) part runs on the matrix core too.  Register r of an acc tile holds
+// rows 4r..4r+3 (row 4r+g in lane group g), which is at once the B operand "rows 4r.. of X" and the A operand
+// "columns 4r.. of X^T".  Round r:
+//   (1) the 10 upper entries of the 4x4 pivot block go to SGPRs (v_readlane); every lane factors it and lane group g
+//       solves column g of its inverse W4 = L44^{-1} (uniform instruction stream, 4 dependent rsqrt);
+//   (2) one MFMA per tile with A = W4 placed at rows 4r.. replaces rows 4r.. of X (and of Z, which starts as I) by
+//       the finished rows of U (of L^{-1});
+//   (3) one MFMA per tile subtracts the rank-4 product from the rows below (A operand masked to those rows).
+// 16 MFMA + 4 short scalar chains per block instead of 16 elimination steps of 15 v_readlane + 15 v_fma each:
+// 4.2k cycles per block in isolation (tools/probe_diag16.hip), bounded by the pivot chain (about 38 dependent fp64 ops per round).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
+__device__ __forceinline__ d4 diag16(const d4& Xin, double* scr, int lane, PivotAcc& pa, int col0,
+                                     double* Lout, int ldl, int nvalid) {
+  const int g = lane >> 4, c = lane & 15;
+#ifdef HGP_STAMPS
+  const unsigned long long td0 = __builtin_readcyclecounter();
+#endif
+  d4 X = Xin, Z;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Z[r] = (4 * r + g == c) ? 1.0 : 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b0 = 4 * r;
+    // X[4r+i][4r+j] lives in register r of lane 16 i + 4r + j
+    const double x00 = lane_bcast(X[r], b0), x01 = lane_bcast(X[r], b0 + 1), x02 = lane_bcast(X[r], b0 + 2),
+                 x03 = lane_bcast(X[r], b0 + 3), x11 = lane_bcast(X[r], 16 + b0 + 1), x12 = lane_bcast(X[r], 16 + b0 + 2),
+                 x13 = lane_bcast(X[r], 16 + b0 + 3), x22 = lane_bcast(X[r], 32 + b0 + 2),
+                 x23 = lane_bcast(X[r], 32 + b0 + 3), x33 = lane_bcast(X[r], 48 + b0 + 3);
+    const double p0 = x00;
+    const double r0 = rsqrt_nr(p0);
+    const double u01 = x01 * r0, u02 = x02 * r0, u03 = x03 * r0;
+    const double p1 = fma(-u01, u01, x11);
+    const double r1 = rsqrt_nr(p1);
+    const double u12 = fma(-u01, u02, x12) * r1, u13 = fma(-u01, u03, x13) * r1;
+    const double p2 = fma(-u12, u12, fma(-u02, u02, x22));
+    const double r2 = rsqrt_nr(p2);
+    const double u23 = fma(-u12, u13, fma(-u02, u03, x23)) * r2;
+    const double p3 = fma(-u23, u23, fma(-u13, u13, fma(-u03, u03, x33)));
+    const double r3 = rsqrt_nr(p3);
+    // NaN compares false; a bad pivot then poisons the outputs with NaN, info says where
+    if (pa.info == 0) {
+      if (!(p0 > 0.0)) pa.info = col0 + b0 + 1;
+      else if (!(p1 > 0.0)) pa.info = col0 + b0 + 2;
+      else if (!(p2 > 0.0)) pa.info = col0 + b0 + 3;
+      else if (!(p3 > 0.0)) pa.info = col0 + b0 + 4;
+    }
+    pa.mant *= (p0 * p1) * (p2 * p3);   // four pivots between renormalisations: no over/underflow for |log2 piv| < 250
+    pa.renorm();
+    // column g of W4 = L44^{-1}: forward substitution of e_g (L44 = U44^T)
+    const double e0 = (g == 0) ? 1.0 : 0.0, e1 = (g == 1) ? 1.0 : 0.0, e2 = (g == 2) ? 1.0 : 0.0, e3 = (g == 3) ? 1.0 : 0.0;
+    const double w0 = e0 * r0;
+    const double w1 = fma(-u01, w0, e1) * r1;
+    const double w2 = fma(-u12, w1, fma(-u02, w0, e2)) * r2;
+    const double w3 = fma(-u23, w2, fma(-u13, w1, fma(-u03, w0, e3))) * r3;
+    // A operand: A[i][kk] = W4[i - 4r][kk] for 4r <= i < 4r + 4, else 0; lane (g, c) holds A[c][g]
+    const int ci = c & 3;
+    double aw = (ci == 0) ? w0 : (ci == 1) ? w1 : (ci == 2) ? w2 : w3;
+    aw = ((c >> 2) == r) ? aw : 0.0;
+    d4 tX = X, tZ = Z;
+    tX[r] = 0.0;
+    tZ[r] = 0.0;
+    tX = mfma(aw, X[r], tX);   // rows 4r.. := W4 * rows 4r..  (the other rows pass through)
+    tZ = mfma(aw, Z[r], tZ);
+    if (r < 3) {
+      const double am = (c >= b0 + 4) ? tX[r] : 0.0;   // rows below the pivot block only
+      X = mfma_sub(am, tX[r], tX);
+      Z = mfma_sub(am, tZ[r], tZ);
+    } else {
+      X = tX;
+      Z = tZ;
+    }
+  }
+  if (Lout != nullptr && c < nvalid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * r + g;                                  // L[c][i] = U[i][c]
+      if (i < nvalid) Lout[(size_t)c * ldl + i] = (i <= c) ? X[r] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) scr[(4 * r + g) * DIAG_LD + c] = Z[r];   // Z[i][j], i = 4r+g, j = c
+  __builtin_amdgcn_wave_barrier();
+  d4 w;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) w[s] = scr[c * DIAG_LD + 4 * s + g];                // W[c][4s+g]
+  __builtin_amdgcn_wave_barrier();
+#ifdef HGP_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  pa.diag_cycles += __builtin_readcyclecounter() - td0;
+#endif
+  return w;
+}
+
+// The all-VALU form of the same block (column j of U in lane j, column j of Z = L^{-1} in lane 16 + j, 16 elimination
+// steps of 15 v_readlane + 15 v_fma): the same ~4.2k cycles in isolation (tools/probe_diag16.hip) with ~20 fewer live
+// registers, which is what the T = 128 single-matrix kernel (k_wave_score1<8>, 36 resident tiles) needs to avoid spills.
+__device__ __forceinline__ d4 diag16_valu(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
                                      double* Lout, int ldl, int nvalid) {
   const int g = lane >> 4, c = lane & 15;
 #ifdef HGP_STAMPS
@@ -189,7 +283,7 @@ __device__ __forceinline__ d4 diag16(const d4& X, double* scr, int lane, PivotAc
 // RHSMODE: 0 = none; 1 = one block column of 16 right-hand sides as MFMA tiles R[K]; 2 = ONE right-hand side kept
 // as a vector in LDS (dvec[16 NB], per wave) and eliminated on the VALU next to the MFMA stream: on exit dvec
 // holds z = L^{-1} d and the return value is z^T z (valid in every lane).
-template <int NB, int RHSMODE>
+template <int NB, int RHSMODE, bool DIAG_VALU = false>
 __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[NB], double* scr, double* Wlds,
                                               double* dvec, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n) {
   constexpr bool RHS = (RHSMODE == 1);
@@ -199,7 +293,8 @@ __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;
     double* Ld = (Lout != nullptr) ? Lout + (size_t)(16 * K) * ldl + 16 * K : nullptr;
-    const d4 W = diag16(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
+    const d4 W = DIAG_VALU ? diag16_valu(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K)
+                           : diag16(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
     if (Wlds != nullptr) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) Wlds[(K * 4 + s) * 64 + lane] = W[s];
