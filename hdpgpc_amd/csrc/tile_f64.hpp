@@ -594,10 +594,16 @@ __device__ __forceinline__ void coop_add_diag(d4 (&U)[Coop<NB>::NT], double shif
 
 // Factor (and eliminate the 16 right-hand sides held as tiles in Rbuf when RHS).  On exit Rbuf holds Z = L^{-1} R.
 // pa accumulates only the pivots of the columns this wave owns; combine with coop_logdet_info.
-template <int NB, bool RHS>
-__device__ __forceinline__ void coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbuf, double* Rbuf, double* Wbuf, double* scr,
-                                            int wave, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n) {
+// RHSMODE: 0 none; 1 = 16 right-hand sides as tiles in Rbuf; 2 = ONE right-hand side as a vector dvec[16 NB] in LDS,
+// eliminated on the VALU by the wave that owns the matching block column (on exit dvec = z = L^{-1} d and the return
+// value is this wave's share of z^T z: sum the four waves' values).
+template <int NB, int RHSMODE>
+__device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbuf, double* Rbuf, double* Wbuf, double* scr,
+                                              int wave, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n,
+                                              double* dvec = nullptr) {
   using C = Coop<NB>;
+  constexpr bool RHS = (RHSMODE == 1);
+  double zq = 0.0;
 #pragma unroll
   for (int K = 0; K < NB; ++K) {
     constexpr int dummy = 0;
@@ -616,6 +622,17 @@ __device__ __forceinline__ void coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbu
 #pragma unroll
         for (int s = 0; s < 4; ++s) z = mfma(Wd[s], rk[s], z);
         lds_tile_store(Rbuf, K, lane, z);
+      }
+      if (RHSMODE == 2) {   // z_K = W d_K : lane (g,c) sums W[c][4s+g] d[4s+g] over s, rows are summed over g
+        double p = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) p = fma(Wd[s], dvec[16 * K + 4 * s + g], p);
+        p = xrow_sum(p);
+        __builtin_amdgcn_wave_barrier();
+        if (g == 0) {
+          dvec[16 * K + c] = p;
+          zq = fma(p, p, zq);
+        }
       }
     }
     __syncthreads();
@@ -639,6 +656,22 @@ __device__ __forceinline__ void coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbu
             const int row = 16 * J + c, col = 16 * K + g + 4 * r;
             if (row < n && col < n) Lout[(size_t)row * ldl + col] = acc[r];
           }
+        }
+      }
+    }
+    if (RHSMODE == 2) {   // d_J -= U_KJ^T z_K for my columns J > K (nobody else touches those 16 entries)
+      double zr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zr[r] = dvec[16 * K + g + 4 * r];
+#pragma unroll
+      for (int q = qK; q < C::NQ; ++q) {
+        const int J = 4 * q + wave;
+        if (J > K && J < NB) {
+          double t = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t = fma(U[C::loc(K, q)][r], zr[r], t);
+          t = xrow_sum(t);
+          if (g == 0) dvec[16 * J + c] -= t;
         }
       }
     }
@@ -674,6 +707,7 @@ __device__ __forceinline__ void coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbu
     }
   }
   __syncthreads();
+  return zq;
 }
 
 // combine the per-wave pivot accumulators: returns log det in every thread, info = first failing column (or 0)

@@ -275,6 +275,38 @@ def test_large_T_pairs(T):
     assert rel_err(logdet.cpu().numpy(), ld_ref) < RT_PAIR
 
 
+@pytest.mark.parametrize("T,N", [(150, 720), (256, 40)])
+def test_large_T_pairs_arbitrary_grids_and_selection(T, N):
+    """Cooperative kernel (one workgroup per pair): E lives in LDS as a list of active 16x16 blocks; grids without
+    band structure (permuted, reversed) activate more blocks than fit and spill to the workgroup's global scratch
+    area.  More pairs than areas can be in flight at once exercises the hand-out / release of those areas.  `sel`
+    scores every segment against one cluster only."""
+    K = 3
+    b = orc.synthetic_batch(N, K, T, seed=77 + T)
+    rng = np.random.default_rng(5)
+    x = b["x"].copy()
+    for n in range(0, N, 4):
+        x[n] = rng.permutation(x[n])           # no band structure: every block of E is active
+    x[1] = x[1][::-1].copy()                    # anti-diagonal band
+    x[2] = x[2] + 61.0                          # shifted band
+    x[3] = x[3] + 5000.0                        # nothing active
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    quad, logdet, info = plan.loglik(dev(x), dev(b["y"]))
+    assert int(info.abs().max()) == 0
+    _, q_ref, ld_ref = orc.loglik_pairs(x, b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
+    assert rel_err(quad.cpu().numpy(), q_ref) < RT_PAIR
+    assert rel_err(logdet.cpu().numpy(), ld_ref) < RT_PAIR
+    sel = torch.as_tensor(rng.integers(0, K, N), dtype=torch.int32, device="cuda")
+    q1, l1, i1 = plan.loglik(dev(x), dev(b["y"]), sel=sel)
+    idx = sel.cpu().numpy()
+    assert int(i1.abs().max()) == 0
+    assert rel_err(q1.cpu().numpy(), q_ref[np.arange(N), idx]) < RT_PAIR
+    assert rel_err(l1.cpu().numpy(), ld_ref[np.arange(N), idx]) < RT_PAIR
+    # a second call on the same plan: every scratch area must have been released
+    q2, _, _ = plan.loglik(dev(x), dev(b["y"]))
+    assert torch.equal(q2, quad)
+
+
 @pytest.mark.parametrize("T", [8, 33, 90, 128])
 def test_score_each_own_state_per_segment(T):
     rng = np.random.default_rng(40 + T)

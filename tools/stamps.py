@@ -24,3 +24,20 @@ for (N, K, T) in [(2048, 8, 128), (2048, 8, 96)]:
     for nme, val in zip(names, v):
         print(f"   {nme:18s} {val:10.0f}")
     print(f"   total              {v[:6].sum():10.0f}")
+
+# cooperative kernel (one workgroup per pair), last wave's view
+for (N, K, T) in [(256, 16, 256), (256, 16, 192)]:
+    b = orc.synthetic_batch(N, K, T)
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    x, y = dev(b["x"]), dev(b["y"])
+    plan.loglik(x, y); torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 8)()
+    ffi.lib.hgp_debug_stamps(buf)
+    plan.loglik(x, y); torch.cuda.synchronize()
+    ffi.lib.hgp_debug_stamps(buf)
+    v = np.array(list(buf), dtype=np.float64) / (N * K)
+    names = ["setup + E build", "d=y-E^T a'", "K** init", "sweep1 (M'E)", "sweep2 (E^T B)", "regularise", "factor+solve", "-"]
+    print(f"coop T={T}: cycles per pair (wave 3 of the workgroup)")
+    for nme, val in zip(names, v):
+        print(f"   {nme:18s} {val:10.0f}")
+    print(f"   total              {v[:7].sum():10.0f}")
