@@ -753,7 +753,7 @@ struct PrepFinalArgs {
   int T, TP;
   double* Mp;           // [K,TP,TP]
   double* ap;           // [K,TP]
-  int interleave;       // 1: tile-pair interleaved columns (fused pairs kernel); 0: plain row-major (staged large-T path)
+  int interleave;       // 1: tile-pair interleaved columns (fused pairs kernel); 0: plain row-major (cooperative pairs kernel)
 };
 
 __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 
 // ------------------------------------------------------------ a2 + a5, cooperative: one workgroup per pair
 // For 128 < T <= 256 a pair does not fit one wave (136 tiles at T = 256).  Here the 4 waves of a workgroup share ONE
-// (segment, cluster) pair: the covariance tiles are dealt column-cyclically (tile (I, J) lives in wave J % 4, at most
+// (segment, cluster) pair: the covariance tiles are dealt by block column in snake order (Coop::owner(J)), at most
 // 40 tiles = 320 VGPR per wave), each wave builds the tiles of its own block columns (K** + two MFMA sweeps, no
 // exchange), then the workgroup factors cooperatively (coop_factor: diagonal block by its owner, row panel and
 // trailing update by column owner, two barriers per step) with the single right-hand side d eliminated on the VALU.
@@ -1169,6 +1169,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
   using C = Coop<NB>;
   using PC = PairsCoop<NB>;
   constexpr int TP = 16 * NB, CAP = PC::CAP, NQ = C::NQ;
+  constexpr int CH = (NB == 16) ? 2 : 4;   // row tiles of B[:, J] per pass (register budget: 40 resident tiles at NB = 16)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ec = smem;                    // [CAP][4][64]
   double* rowbuf = Ec + CAP * 256;      // [NB][4][64]
@@ -1301,8 +1302,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
   }
   __syncthreads();
   // E[16 Kt + 4 s + g][16 Jb + c] of the block in `slot`: the B operand of sweep 1 (k-step s) and the A operand of sweep 2
+  // (the overflow read is a volatile global load on purpose: with two plain loads the compiler merges the branches
+  //  into ONE flat_load through a selected generic pointer, which costs the LDS path its ds_read and its wait counter)
   auto e_op = [&](int slot, int s) -> double {
-    return (slot < CAP) ? Ec[slot * 256 + s * 64 + lane] : Eov[(size_t)(slot - CAP) * 256 + s * 64 + lane];
+    if (slot < CAP) return Ec[slot * 256 + s * 64 + lane];
+    return *reinterpret_cast<const volatile double*>(Eov + (size_t)(slot - CAP) * 256 + s * 64 + lane);
   };
   auto release_area = [&]() {
     if (my_area >= 0) {
@@ -1369,7 +1373,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
   d4 U[C::NT];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int J = 4 * q + wave;
+    const int J = C::col(q, wave);
     const int mJ = __builtin_amdgcn_readfirstlane(amask[J]), bJ = __builtin_amdgcn_readfirstlane(base[J]);
     const int kmJ = __builtin_amdgcn_readfirstlane(kmask[J]), need = __builtin_amdgcn_readfirstlane(pneed[J]);
     // K** = c exp(-0.5 (x_i - x_j)^2) + noise I on my column (the one-argument kernel call, GPI.py:476)
@@ -1395,25 +1399,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
     }
     HGP_ACC(2);
 #pragma nounroll
-    for (int h = 0; h < NB / 4; ++h) {
-      const int nb4 = (need >> (4 * h)) & 15;
+    for (int h = 0; h < NB / CH; ++h) {
+      const int nb4 = (need >> (CH * h)) & ((1 << CH) - 1);
       if (!nb4) continue;
       // sweep 1: BJ[i] = M'[rows of tile 4h + i, :] E[:, J] over the active blocks of column J.  M' is symmetric:
       // the A operand of output row tile i, k-step s of block Kt is M'[16 Kt + 4 s + g][16 (4h + i) + c] (coalesced).
-      d4 BJ[4];
+      d4 BJ[CH];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) BJ[i] = (d4){0.0, 0.0, 0.0, 0.0};
-      const double* Mh = Mk + (size_t)g * TP + 64 * h + c;
-      double ra[2][4][4], re[2][4];
+      for (int i = 0; i < CH; ++i) BJ[i] = (d4){0.0, 0.0, 0.0, 0.0};
+      const double* Mh = Mk + (size_t)g * TP + 16 * CH * h + c;
+      double ra[2][4][CH], re[2][4];
 #define HGP_CFILL(buf, Kt_, slot_)                                                                  \
   _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
     const double* row_ = Mh + (size_t)(16 * (Kt_) + 4 * s_) * TP;                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ra[buf][s_][i_] = row_[16 * i_];               \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) ra[buf][s_][i_] = row_[16 * i_];               \
     re[buf][s_] = e_op((slot_), s_);                                                                 \
   }
 #define HGP_CMMA(buf)                                                                               \
   _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_)                                               \
       if (nb4 & (1 << i_)) BJ[i_] = mfma(ra[buf][s_][i_], re[buf][s_], BJ[i_]);                     \
   }
       int m = mJ, slot = bJ;
@@ -1449,12 +1453,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
       // of all its active blocks in this chunk are requested first, then multiplied: one LDS latency per tile.
 #pragma unroll
       for (int I = 0; I < 4 * q + 4; ++I) {
-        const int m4 = (msk[I] >> (4 * h)) & nb4;
+        const int m4 = (msk[I] >> (CH * h)) & nb4;
         if (I <= J && m4) {
-          const int below = __popc(msk[I] & ((1 << (4 * h)) - 1));
-          double af[4][4];
+          const int below = __popc(msk[I] & ((1 << (CH * h)) - 1));
+          double af[CH][4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < CH; ++i) {
             if (m4 & (1 << i)) {
               const int slot2 = bas[I] + below + __popc(m4 & ((1 << i) - 1));
 #pragma unroll
@@ -1462,7 +1466,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
             }
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < CH; ++i) {
             if (m4 & (1 << i)) {
 #pragma unroll
               for (int s = 0; s < 4; ++s) U[C::loc(I, q)] = mfma(af[i][s], BJ[i][s], U[C::loc(I, q)]);
@@ -1499,8 +1503,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
   release_area();
   HGP_ACC(6);
 #ifdef HGP_STAMPS
-  if (tid == 64 * (WAVES - 1) && a.stamps)   // the view of the wave with the most tiles
+  if (tid == 64 * (WAVES - 1) && a.stamps) {   // the view of the last wave
     for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
+    for (int i = 0; i < 5; ++i) atomicAdd(&a.stamps[8 + i], pa.cf[i]);
+  }
 #endif
 }
 
@@ -1515,89 +1521,6 @@ int launch_pairs_coop(const PairsArgs& a, hipStream_t st) {
   const int blocks = a.sel ? a.N : a.N * (a.kend - a.kbeg);
   hipLaunchKernelGGL(k_pairs_coop<NB>, dim3(blocks), dim3(64 * WAVES), lds, st, a);
   return launch_status();
-}
-
-// ---------------------------------------------------------------- a2 + a5 for 128 < T <= 256 (HBM-staged)
-// The register/LDS-resident pairs kernel cannot hold a 256 x 256 pair.  For these sizes the same algebra runs as a
-// pipeline over chunks of segments with the intermediates in HBM: E -> B = M' E -> C = E^T B -> cov -> cooperative
-// factor/solve.  Correct and general; its traffic (about 3 TP^2 doubles written and read per pair) is what the fused
-// kernel avoids, so it is a stop-gap for the large-T configuration, not the design point.
-struct BigArgs {
-  const double* x;
-  const double* y;
-  int n0, nc, Ts, T, TP, K;
-  const double* xb;
-  const double* scal;
-  const double* ap;
-  const int32_t* perm;
-  int kbeg, kend;
-  double ell;
-  const double* first_noise;
-  double* E;      // [nc, TP, TP]
-  double* C;      // [nc, K, TP, TP]  (E^T M' E, then the finished covariance)
-  double* f;      // [nc, K, TP]      (E^T a', then d = y - f)
-  int32_t* item_mat;
-  int32_t* item_off;
-  int32_t* item_cnt;
-  double* item_add;
-};
-
-__global__ __launch_bounds__(256) void k_big_E(BigArgs a) {
-  const int nl = blockIdx.y;
-  const size_t n = (size_t)a.n0 + nl;
-  const int TP = a.TP;
-  double* E = a.E + (size_t)nl * TP * TP;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < TP * TP; idx += gridDim.x * 256) {
-    const int k = idx / TP, j = idx % TP;
-    double v = 0.0;
-    if (k < a.T && j < a.Ts) {
-      const double u = a.xb[k] / a.ell - a.x[n * a.Ts + j] / a.ell;
-      v = exp(-0.5 * (u * u));
-    }
-    E[idx] = v;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_big_finish(BigArgs a) {
-  const int nl = blockIdx.y, kk = a.kbeg + blockIdx.z;
-  const int kc = a.perm[kk];
-  const size_t n = (size_t)a.n0 + nl;
-  const int TP = a.TP, Ts = a.Ts;
-  const double* sc = a.scal + 8 * kc;
-  const double cc = sc[0], noise = sc[2];
-  const bool iso = sc[3] != 0.0;
-  const size_t p = (size_t)nl * a.K + kc;
-  double* C = a.C + p * TP * TP;
-  const double* xr = a.x + n * Ts;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < TP * TP; idx += gridDim.x * 256) {
-    const int i = idx / TP, j = idx % TP;
-    if (j < i) continue;                              // the factor kernels symmetrise on load: fill both halves
-    double v;
-    if (i < Ts && j < Ts) {
-      if (iso) {
-        v = (i == j) ? sc[4] : 0.0;
-      } else {
-        const double u = xr[i] / a.ell - xr[j] / a.ell;
-        const double kss = (i == j) ? cc + noise : cc * exp(-0.5 * (u * u));
-        v = kss + 0.5 * (C[(size_t)i * TP + j] + C[(size_t)j * TP + i]);
-      }
-    } else {
-      v = (i == j) ? 1.0 : 0.0;
-    }
-    C[(size_t)i * TP + j] = v;
-    C[(size_t)j * TP + i] = v;
-  }
-  if (blockIdx.x == 0) {
-    double* f = a.f + p * TP;
-    for (int j = threadIdx.x; j < TP; j += 256) f[j] = (j < Ts) ? a.y[n * Ts + j] - f[j] : 0.0;
-    if (threadIdx.x == 0) {
-      const double fn = a.first_noise ? a.first_noise[n * a.K + kc] : 0.0;
-      a.item_mat[p] = (int32_t)p;
-      a.item_off[p] = (int32_t)p;
-      a.item_cnt[p] = 1;
-      a.item_add[p] = (iso ? 0.0 : 1e-6) + fn;
-    }
-  }
 }
 
 template <int NB>
@@ -1626,12 +1549,7 @@ struct hgp_pairs_plan {
   // device carve-up
   double *d_theta, *d_scal, *d_A, *d_S, *d_Z, *d_Kinv, *d_P, *d_Q, *d_Mp, *d_ap, *d_xb;
   int32_t* d_perm;
-  // 128 < T: HBM-staged pipeline, chunk of `nchunk` segments
-  bool big = false;
   bool coop = false;   // one workgroup per pair (k_pairs_coop): always for T > 128
-  int nchunk = 0;
-  double *d_E = nullptr, *d_C = nullptr, *d_f = nullptr, *d_iadd = nullptr, *d_q = nullptr, *d_ld = nullptr;
-  int32_t *d_imat = nullptr, *d_ioff = nullptr, *d_icnt = nullptr, *d_iinfo = nullptr;
   // cooperative kernel: overflow areas for the E blocks of dense grids
   double* d_escr = nullptr;
   int32_t* d_eflags = nullptr;
@@ -1643,9 +1561,7 @@ static int tp_for(int n) {   // padded size: wave kernels {32,64,96,128}, cooper
   if (n <= HGP_MAX_T_WAVE) return 16 * nb_for(n);
   return n <= 192 ? 192 : 256;
 }
-static const int BIG_CHUNK = 32;
-// Diagnostic switches (read when a plan is created): HGP_PAIRS_COOP=1 runs the cooperative kernel for T <= 128 too;
-// HGP_PAIRS_STAGED=1 runs the HBM-staged pipeline for T > 128 (the first implementation, kept for comparison).
+// Diagnostic switch (read when a plan is created): HGP_PAIRS_COOP=1 runs the cooperative kernel for T <= 128 too.
 static bool env_on(const char* name) {
   const char* v = getenv(name);
   return v && v[0] && v[0] != '0';
@@ -1684,19 +1600,6 @@ static size_t plan_bytes(int T, int Ts_max, int K, size_t* offs /*[24]*/) {
     const size_t nscr = over ? (nb >= 12 ? 512 : 1024) : 0;
     tmp[22] = take(nscr * over * 256 * sizeof(double));
     tmp[23] = take((nscr + 1) * sizeof(int32_t));
-  }
-  if (TP > HGP_MAX_T_WAVE && env_on("HGP_PAIRS_STAGED")) {
-    const size_t np = (size_t)BIG_CHUNK * K;
-    tmp[12] = take((size_t)BIG_CHUNK * TP * TP * sizeof(double));   // E
-    tmp[13] = take(2 * np * TP * TP * sizeof(double));              // C / cov  +  B = M' E scratch
-    tmp[14] = take(np * TP * sizeof(double));                       // f / d
-    tmp[15] = take(np * sizeof(double));                            // item_add
-    tmp[16] = take(np * sizeof(int32_t));                           // item_mat
-    tmp[17] = take(np * sizeof(int32_t));                           // item_off
-    tmp[18] = take(np * sizeof(int32_t));                           // item_cnt
-    tmp[19] = take(np * sizeof(double));                            // quad
-    tmp[20] = take(np * sizeof(double));                            // logdet
-    tmp[21] = take(np * sizeof(int32_t));                           // info
   }
   if (offs) memcpy(offs, tmp, sizeof(tmp));
   return o;
@@ -1783,9 +1686,7 @@ int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const
   p->K = K;
   p->TP = tp_plan(std::max(T, Ts_max));
   p->NB = p->TP / 16;
-  p->big = p->TP > HGP_MAX_T_WAVE && env_on("HGP_PAIRS_STAGED");
-  p->coop = !p->big && (p->TP > HGP_MAX_T_WAVE || env_on("HGP_PAIRS_COOP"));
-  p->nchunk = BIG_CHUNK;
+  p->coop = p->TP > HGP_MAX_T_WAVE || env_on("HGP_PAIRS_COOP");
   p->theta.assign(theta_host, theta_host + 3 * (size_t)K);
   p->perm.resize(K);
   for (int k = 0; k < K; ++k) p->perm[k] = k;
@@ -1813,18 +1714,6 @@ int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const
   p->d_ap = (double*)(base + offs[9]);
   p->d_perm = (int32_t*)(base + offs[10]);
   p->d_xb = (double*)(base + offs[11]);
-  if (p->big) {
-    p->d_E = (double*)(base + offs[12]);
-    p->d_C = (double*)(base + offs[13]);
-    p->d_f = (double*)(base + offs[14]);
-    p->d_iadd = (double*)(base + offs[15]);
-    p->d_imat = (int32_t*)(base + offs[16]);
-    p->d_ioff = (int32_t*)(base + offs[17]);
-    p->d_icnt = (int32_t*)(base + offs[18]);
-    p->d_q = (double*)(base + offs[19]);
-    p->d_ld = (double*)(base + offs[20]);
-    p->d_iinfo = (int32_t*)(base + offs[21]);
-  }
   if (p->coop) {
     const size_t cap = (p->NB >= 12) ? 48 : (p->NB == 8 ? 24 : 16);
     const size_t over = (size_t)p->NB * p->NB > cap ? (size_t)p->NB * p->NB - cap : 0;
@@ -1875,7 +1764,7 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   launch_gemm(g1, K, st);
   launch_gemm(g2, K, st);
   launch_gemm(g3, K, st);
-  PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap, (p->big || p->coop) ? 0 : 1};
+  PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap, p->coop ? 0 : 1};
   hipLaunchKernelGGL(k_prep_final, dim3(K, 8), dim3(256), 0, st, fin);
   return launch_status();
 }
@@ -1889,41 +1778,6 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
   if (Ts > p->TP) return -2;   // plan was created with a smaller Ts_max
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  if (p->big) {
-    if (sel) return -2;                 // per-segment selection is only wired into the fused kernel
-    const int TP = p->TP, K = p->K;
-    const long tt = (long)TP * TP;
-    for (int n0 = 0; n0 < N && rc == 0; n0 += p->nchunk) {
-      const int nc = std::min(p->nchunk, N - n0);
-      for (size_t gi = 0; gi < p->grp_beg.size() && rc == 0; ++gi) {
-        const int kb = p->grp_beg[gi], ke = p->grp_end[gi], kg = ke - kb;
-        BigArgs a{x, y, n0, nc, Ts, p->T, TP, K, p->d_xb, p->d_scal, p->d_ap, p->d_perm, kb, ke, p->grp_ell[gi],
-                  first_noise, p->d_E, p->d_C, p->d_f, p->d_imat, p->d_ioff, p->d_icnt, p->d_iadd};
-        hipLaunchKernelGGL(k_big_E, dim3(16, nc), dim3(256), 0, st, a);
-        // the clusters of a length-scale group are not contiguous in cluster id: one GEMM batch per cluster
-        for (int kk = kb; kk < ke && rc == 0; ++kk) {
-          const int kc = p->perm[kk];
-          double* Ck = p->d_C + (size_t)kc * tt;                                     // pair (nl, kc): stride K tt
-          double* Bk = p->d_C + (size_t)(p->nchunk * K) * tt + (size_t)kc * tt;     // second half of the chunk buffer
-          GemmArgs g1{p->d_Mp + (size_t)kc * tt, p->d_E, Bk, TP, TP, TP, TP, TP, TP, 0, tt, (long)K * tt, 1.0, 0.0, 0, 0};   // B = M' E
-          if ((rc = launch_gemm(g1, nc, st))) break;
-          GemmArgs g2{p->d_E, Bk, Ck, TP, TP, TP, TP, TP, TP, tt, (long)K * tt, (long)K * tt, 1.0, 0.0, 1, 0};               // C = E^T B
-          if ((rc = launch_gemm(g2, nc, st))) break;
-          GemmArgs g3{p->d_E, p->d_ap + (size_t)kc * TP, p->d_f + (size_t)kc * TP, TP, 1, TP, TP, 1, 1, tt, 0, (long)K * TP, 1.0, 0.0, 1, 0};
-          if ((rc = launch_gemm(g3, nc, st))) break;
-        }
-        if (rc) break;
-        hipLaunchKernelGGL(k_big_finish, dim3(8, nc, kg), dim3(256), 0, st, a);
-      }
-      if (rc) break;
-      // every pair of the chunk is one work item of the cooperative score kernel (T = Ts inside TP x TP storage)
-      ScoreArgs sa{p->d_f, TP, nullptr, 0, p->d_C, tt, Ts, TP, p->d_imat, nullptr, p->d_iadd, p->d_ioff, p->d_icnt, nc * K,
-                   nullptr, 1e-8, out_quad + (size_t)n0 * K, out_logdet ? out_logdet + (size_t)n0 * K : nullptr,
-                   out_info ? out_info + (size_t)n0 * K : nullptr};
-      rc = (TP == 192) ? launch_coop_score<12>(sa, st) : launch_coop_score<16>(sa, st);
-    }
-    return rc;
-  }
   for (size_t gi = 0; gi < p->grp_beg.size() && rc == 0; ++gi) {
     PairsArgs a{x, y, N, Ts, p->d_xb, p->T, p->d_Mp, p->d_ap, p->d_scal, p->d_perm, p->grp_beg[gi], p->grp_end[gi],
                 p->grp_ell[gi], first_noise, sel,
@@ -2053,11 +1907,11 @@ int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, dou
 // diagnostic build: read and reset the phase cycle sums (d/f*, sweep 1, K** init, sweep 2, regularise, factor, -, diag16)
 int hgp_debug_stamps(unsigned long long* out8_host) {
   if (!g_stamp_dev) {
-    if (hipMalloc(&g_stamp_dev, 64) != hipSuccess) return 1;
-    (void)hipMemset(g_stamp_dev, 0, 64);
+    if (hipMalloc(&g_stamp_dev, 128) != hipSuccess) return 1;
+    (void)hipMemset(g_stamp_dev, 0, 128);
   }
-  if (hipMemcpy(out8_host, g_stamp_dev, 64, hipMemcpyDeviceToHost) != hipSuccess) return 1;
-  (void)hipMemset(g_stamp_dev, 0, 64);
+  if (hipMemcpy(out8_host, g_stamp_dev, 128, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  (void)hipMemset(g_stamp_dev, 0, 128);
   return 0;
 }
 #endif

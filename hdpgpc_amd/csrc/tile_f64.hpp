@@ -98,8 +98,8 @@ struct PivotAcc {
   int ex;
   int info;  // 0 = ok, j > 0 = pivot j (1-based) was not positive
 #ifdef HGP_STAMPS
-  unsigned long long diag_cycles;
-  __device__ __forceinline__ void init() { mant = 1.0; ex = 0; info = 0; diag_cycles = 0; }
+  unsigned long long diag_cycles, cf[5];
+  __device__ __forceinline__ void init() { mant = 1.0; ex = 0; info = 0; diag_cycles = 0; for (int i = 0; i < 5; ++i) cf[i] = 0; }
 #else
   __device__ __forceinline__ void init() { mant = 1.0; ex = 0; info = 0; }
 #endif
@@ -492,7 +492,7 @@ __device__ __forceinline__ double diag_abs_mean(const d4 (&U)[NB * (NB + 1) / 2]
 
 // =============================================================================================
 // 4-wave cooperative version for 128 < T <= 256 (NB <= 16 tiles): the upper tiles are dealt
-// column-cyclically to the 4 waves of a workgroup (tile (I, J) lives in wave J % 4), 40 tiles =
+// column-wise to the 4 waves of a workgroup (tile (I, J) lives in wave Coop::owner(J), snake order), 40 tiles =
 // 320 VGPR per wave at NB = 16.  Step K: the owner of column K factors the diagonal block and
 // publishes W through LDS; every wave solves the row-K tiles of its own columns and publishes them
 // (rowbuf); every wave updates its own trailing tiles reading U_KI from rowbuf.  Two workgroup
@@ -504,7 +504,12 @@ struct Coop {
   static_assert(NB % 4 == 0 && NB <= 16, "cooperative factor: NB in {4,8,12,16}");
   static constexpr int NQ = NB / 4;
   static constexpr int NT = 2 * NQ * (NQ + 1);   // tiles per wave (shape of the wave that owns the most)
-  __host__ __device__ static constexpr int loc(int I, int q) { return 2 * q * (q + 1) + I; }   // tile (I, 4q + wave)
+  __host__ __device__ static constexpr int loc(int I, int q) { return 2 * q * (q + 1) + I; }   // tile (I, col(q, wave))
+  // Block columns are dealt to the waves in SNAKE order (0 1 2 3 | 3 2 1 0 | 0 1 2 3 ...): column J costs J + 1 tiles,
+  // so plain cyclic dealing gives the last wave 40 tiles and the first 28 at NB = 16; the snake gives every wave 34,
+  // and the trailing updates of each elimination step are balanced the same way.
+  __host__ __device__ static constexpr int col(int q, int wave) { return 4 * q + ((q & 1) ? 3 - wave : wave); }
+  __host__ __device__ static constexpr int owner(int J) { return ((J >> 2) & 1) ? 3 - (J & 3) : (J & 3); }
   static constexpr int LDS_DOUBLES = NB * 256 /*rowbuf*/ + NB * 256 /*Rbuf*/ + 256 /*Wbuf*/ + DIAG_SCR + 16;
 };
 
@@ -528,7 +533,7 @@ __device__ __forceinline__ void coop_load_sym_upper(d4 (&U)[Coop<NB>::NT], const
     for (int I = 0; I < 4 * q + 4; ++I) {
       const int lane = launder(lane_in);
       const int g = lane >> 4, c = lane & 15;
-      const int J = 4 * q + wave;
+      const int J = Coop<NB>::col(q, wave);
       d4 v = (d4){0.0, 0.0, 0.0, 0.0};
       if (I <= J && J < NB) {
 #pragma unroll
@@ -556,7 +561,7 @@ __device__ __forceinline__ double coop_diag_abs_mean(const d4 (&U)[Coop<NB>::NT]
     for (int I = 4 * q; I < 4 * q + 4; ++I) {
       const int lane = launder(lane_in);
       const int g = lane >> 4, c = lane & 15;
-      if (I == 4 * q + wave) {
+      if (I == Coop<NB>::col(q, wave)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * I + g + 4 * r;
@@ -581,7 +586,7 @@ __device__ __forceinline__ void coop_add_diag(d4 (&U)[Coop<NB>::NT], double shif
     for (int I = 4 * q; I < 4 * q + 4; ++I) {
       const int lane = launder(lane_in);
       const int g = lane >> 4, c = lane & 15;
-      if (I == 4 * q + wave) {
+      if (I == Coop<NB>::col(q, wave)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * I + g + 4 * r;
@@ -604,11 +609,17 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
   using C = Coop<NB>;
   constexpr bool RHS = (RHSMODE == 1);
   double zq = 0.0;
+#ifdef HGP_STAMPS
+  unsigned long long cf_t = __builtin_readcyclecounter();
+#define HGP_CF(i) do { unsigned long long n_ = __builtin_readcyclecounter(); pa.cf[i] += n_ - cf_t; cf_t = n_; } while (0)
+#else
+#define HGP_CF(i)
+#endif
 #pragma unroll
   for (int K = 0; K < NB; ++K) {
     constexpr int dummy = 0;
     (void)dummy;
-    const int qK = K / 4, wK = K % 4;
+    const int qK = K / 4, wK = C::owner(K);
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;
     if (wave == wK) {
@@ -635,14 +646,16 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
         }
       }
     }
+    HGP_CF(0);
     __syncthreads();
+    HGP_CF(1);
     d4 W;
 #pragma unroll
     for (int s = 0; s < 4; ++s) W[s] = Wbuf[s * 64 + lane];
     // panel: U_KJ = W A_KJ for my columns J > K; publish them
 #pragma unroll
     for (int q = qK; q < C::NQ; ++q) {
-      const int J = 4 * q + wave;
+      const int J = Coop<NB>::col(q, wave);
       if (J > K && J < NB) {
         const d4 t = U[C::loc(K, q)];
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
@@ -665,7 +678,7 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
       for (int r = 0; r < 4; ++r) zr[r] = dvec[16 * K + g + 4 * r];
 #pragma unroll
       for (int q = qK; q < C::NQ; ++q) {
-        const int J = 4 * q + wave;
+        const int J = Coop<NB>::col(q, wave);
         if (J > K && J < NB) {
           double t = 0.0;
 #pragma unroll
@@ -675,21 +688,25 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
         }
       }
     }
+    HGP_CF(2);
     __syncthreads();
-    // trailing: A_IJ -= U_KI^T U_KJ for my columns J > K and K < I <= J
+    HGP_CF(3);
+    // trailing: A_IJ -= U_KI^T U_KJ for my columns J >= I > K.  Row tile I of the panel is read from LDS once and
+    // applied to all my columns; the next one is requested before the MFMAs of the current one are issued.
+    if (K + 1 < NB) {
+      d4 ucur = lds_tile_load(rowbuf, K + 1, lane);
 #pragma unroll
-    for (int q = qK; q < C::NQ; ++q) {
-      const int J = 4 * q + wave;
-      if (J > K && J < NB) {
-        const d4 ukj = U[C::loc(K, q)];
+      for (int I = K + 1; I < NB; ++I) {
+        d4 unext = ucur;
+        if (I + 1 < NB) unext = lds_tile_load(rowbuf, I + 1, lane);
 #pragma unroll
-        for (int I = K + 1; I < 4 * q + 4; ++I) {
-          if (I <= J) {
-            const d4 uki = lds_tile_load(rowbuf, I, lane);
+        for (int q = I / 4; q < C::NQ; ++q) {
+          if (C::col(q, wave) >= I) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) U[C::loc(I, q)] = mfma_sub(uki[s], ukj[s], U[C::loc(I, q)]);
+            for (int s = 0; s < 4; ++s) U[C::loc(I, q)] = mfma_sub(ucur[s], U[C::loc(K, q)][s], U[C::loc(I, q)]);
           }
         }
+        ucur = unext;
       }
     }
     if (RHS) {   // R_I -= U_KI^T Z_K for I > K, rows dealt to the waves round-robin
@@ -705,10 +722,12 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
         }
       }
     }
+    HGP_CF(4);
   }
   __syncthreads();
   return zq;
 }
+#undef HGP_CF
 
 // combine the per-wave pivot accumulators: returns log det in every thread, info = first failing column (or 0)
 __device__ __forceinline__ double coop_logdet_info(const PivotAcc& pa, int wave, int lane, double* red, int* redi, int& info) {

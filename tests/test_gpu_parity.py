@@ -223,7 +223,7 @@ def test_pairs_block_skipping_on_arbitrary_grids():
     assert rel_err(logdet.cpu().numpy(), ld_ref) < RT_PAIR
 
 
-# ------------------------------------------------------------------ 128 < T <= 256: cooperative kernels + staged pipeline
+# ------------------------------------------------------------------ 128 < T <= 256: cooperative kernels
 @pytest.mark.parametrize("T", [144, 192, 256])
 def test_large_T_potrf_and_score(T):
     rng = np.random.default_rng(T)
@@ -263,7 +263,7 @@ def test_large_T_pairs(T):
     N, K = 3, 2
     b = orc.synthetic_batch(N, K, T, seed=900 + T)
     if T == 160:
-        b["Sigma"][1] = 2.2 * np.eye(T)                   # iso branch through the staged pipeline
+        b["Sigma"][1] = 2.2 * np.eye(T)                   # iso branch of the cooperative kernel
     fn = np.zeros((N, K))
     fn[0, 0] = 0.04
     plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))

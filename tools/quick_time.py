@@ -30,13 +30,13 @@ for (S,T) in [(4096,128),(4096,90),(4096,64)]:
     t=timeit(lambda: ops.score_groups(Y,mean,Sig,*items))
     print(f"score_groups S={S} T={T}: {t*1e3:.3f} ms -> {S/t:.3e} evals/s, {S*T*T*8/t/1e9:.1f} GB/s", flush=True)
 
-for (N,K,T) in [(256,16,256)]:
+for (N,K,T) in [(256,16,256),(1024,16,256),(256,16,192)]:
     b = orc.synthetic_batch(N,K,T)
     plan = ops.PairsPlan(T,T,b["theta"])
     xb,mean,Sig,x,y = dev(b["xb"]),dev(b["mean"]),dev(b["Sigma"]),dev(b["x"]),dev(b["y"])
     tu = timeit(lambda: plan.update(xb,mean,Sig), n=2, w=1)
     tp = timeit(lambda: plan.loglik(x,y), n=2, w=1)
-    print(f"pairs (staged, large T) N={N} K={K} T={T}: update {tu*1e3:.3f} ms, pairs {tp*1e3:.3f} ms -> {N*K/(tu+tp):.3e} evals/s", flush=True)
+    print(f"pairs (cooperative, large T) N={N} K={K} T={T}: update {tu*1e3:.3f} ms, pairs {tp*1e3:.3f} ms -> {N*K/(tu+tp):.3e} evals/s", flush=True)
 
 for (S,T) in [(4096,128),(4096,90),(4096,64),(16384,90)]:
     rng=np.random.default_rng(0)

@@ -14,7 +14,7 @@ for (N, K, T) in [(2048, 8, 128), (2048, 8, 96)]:
     plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
     x, y = dev(b["x"]), dev(b["y"])
     plan.loglik(x, y); torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 16)()
     ffi.lib.hgp_debug_stamps(buf)           # reset
     plan.loglik(x, y); torch.cuda.synchronize()
     ffi.lib.hgp_debug_stamps(buf)
@@ -31,7 +31,7 @@ for (N, K, T) in [(256, 16, 256), (256, 16, 192)]:
     plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
     x, y = dev(b["x"]), dev(b["y"])
     plan.loglik(x, y); torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 16)()
     ffi.lib.hgp_debug_stamps(buf)
     plan.loglik(x, y); torch.cuda.synchronize()
     ffi.lib.hgp_debug_stamps(buf)
@@ -41,3 +41,4 @@ for (N, K, T) in [(256, 16, 256), (256, 16, 192)]:
     for nme, val in zip(names, v):
         print(f"   {nme:18s} {val:10.0f}")
     print(f"   total              {v[:7].sum():10.0f}")
+    print("   factor split (same wave): diag16+rhs %.0f | wait W %.0f | panel %.0f | wait row %.0f | trailing %.0f" % tuple(v[8:13]))
