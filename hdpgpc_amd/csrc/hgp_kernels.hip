@@ -588,8 +588,15 @@ __global__ void k_warp_cov(const double* __restrict__ x, int T, double rho, doub
   K[idx] = v;
 }
 
-// config 5: L <- chol(alpha L L^T + beta v v^T), one wave per matrix (T <= 256), O(T^2) instead of O(T^3).
-// Classic hyperbolic-free update: for k: r = hypot(L_kk, x_k), c = r / L_kk, s = x_k / L_kk, column k and x updated.
+// config 5: L <- chol(alpha L L^T + beta v v^T) by a rank-1 update, O(T^2) instead of O(T^3); T <= 256.
+// One workgroup per matrix, thread i owns ROW i of L and x_i.  Columns are processed in blocks of 16:
+//   - every thread still below the block loads its 16-entry row segment (the next block's segment is requested
+//     before the current one is processed);
+//   - the wave that holds the 16 pivot rows runs the 16 dependent steps  r = hypot(l_kk, x_k), c = r / l_kk,
+//     s = x_k / l_kk  with the pivot row's values broadcast by v_readlane, applying each rotation to all of its
+//     own rows on the way (one rsqrt on the chain per step; the reciprocals 1 / l_kk are taken off the chain);
+//   - the 16 rotations go to LDS (double-buffered, one barrier per block) and the other waves apply them to their rows.
+// Row segments are read and written once: 8 T^2 bytes of HBM traffic per update (lower triangle in and out).
 struct Rank1Args {
   double* L;
   const double* v;
@@ -599,41 +606,96 @@ struct Rank1Args {
   int32_t* info;
 };
 
-__global__ __launch_bounds__(64 * WAVES) void k_chol_rank1(Rank1Args a) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = blockIdx.x * WAVES + wave;
-  if (m >= a.b) return;
+__global__ __launch_bounds__(256) void k_chol_rank1(Rank1Args a) {
+  __shared__ double rot[2][16][4];   // (1/c, s, c) of the 16 steps of a block
+  __shared__ int s_info;
+  const int i = threadIdx.x, lane = i & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
+  const int m = blockIdx.x;
   const int T = a.T;
   double* L = a.L + (size_t)m * T * T;
   const double al = a.alpha ? a.alpha[m] : 1.0, be = a.beta ? a.beta[m] : 1.0;
   const double sa = sqrt(al), sb = sqrt(be);
-  double x[4];
+  double x = (i < T) ? sb * a.v[(size_t)m * T + i] : 0.0;
+  if (i == 0) s_info = (al > 0.0 && be >= 0.0) ? 0 : -1;
+  int info = 0;
+  const int nblk = (T + 15) >> 4;
+  double cur[16], nxt[16];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = lane + 64 * q;
-    x[q] = (i < T) ? sb * a.v[(size_t)m * T + i] : 0.0;
-  }
-  int info = (al > 0.0 && be >= 0.0) ? 0 : -1;
-  for (int k = 0; k < T; ++k) {
-    const int kq = k >> 6;
-    const double xsel = (kq == 0) ? x[0] : (kq == 1) ? x[1] : (kq == 2) ? x[2] : x[3];
-    const double xk = __shfl(xsel, k & 63, 64);
-    const double lkk = sa * L[(size_t)k * T + k];
-    const double r = sqrt(lkk * lkk + xk * xk);
-    if (!(r > 0.0) && info == 0) info = k + 1;
-    const double cinv = lkk / r, s = xk / lkk;       // 1/c and s
-    if (lane == 0) L[(size_t)k * T + k] = r;
+  for (int j = 0; j < 16; ++j) cur[j] = (i < T && j < T && j <= i) ? L[(size_t)i * T + j] : 0.0;
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int k0 = 16 * kb, k1 = k0 + 16;
+    const bool below = i < T && i >= k0;            // rows above the block are final
+    if (kb + 1 < nblk) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = lane + 64 * q;
-      if (i > k && i < T) {
-        const double lik = (sa * L[(size_t)i * T + k] + s * x[q]) * cinv;
-        x[q] = x[q] / cinv - s * lik;                 // c x_i - s L_ik(new)
-        L[(size_t)i * T + k] = lik;
+      for (int j = 0; j < 16; ++j) nxt[j] = (i < T && i >= k1 && k1 + j <= i) ? L[(size_t)i * T + k1 + j] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] *= sa;
+    const int wd = k0 >> 6;                         // the wave that owns the pivot rows k0 .. k0 + 15
+    double (*R)[4] = rot[kb & 1];
+    if (wave == wd) {
+      const int pl0 = k0 & 63;
+      // reciprocal of MY pivot entry (lane pl0 + j holds l_jj in cur[j]), off the dependent chain
+      double mine = 1.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mine = (lane == pl0 + j) ? cur[j] : mine;
+      const double myinv = 1.0 / mine;
+      double rc[16][3];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {   // (columns >= T of the last block hold zeros: l_kk = 0 -> NaN rotations that no row uses)
+        const int pl = pl0 + k;
+        const double lkk = lane_bcast(cur[k], pl), xk = lane_bcast(x, pl), ilkk = lane_bcast(myinv, pl);
+        const double t = fma(lkk, lkk, xk * xk);
+        const double rinv = rsqrt_nr(t);
+        const double r = t * rinv, cinv = lkk * rinv, c = r * ilkk, sn = xk * ilkk;
+        const bool live = k0 + k < T;
+        info = (live && !(r > 0.0) && info == 0) ? k0 + k + 1 : info;
+        // selects, not branches: an exec-mask change per step would sit on the dependent chain
+        const bool upd = live && lane > pl && below;
+        const double ln = fma(sn, x, cur[k]) * cinv;
+        const double xn = fma(c, x, -sn * ln);
+        x = upd ? xn : x;
+        cur[k] = (live && lane == pl) ? r : (upd ? ln : cur[k]);
+        rc[k][0] = cinv;
+        rc[k][1] = sn;
+        rc[k][2] = c;
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          R[k][0] = rc[k][0];
+          R[k][1] = rc[k][1];
+          R[k][2] = rc[k][2];
+        }
       }
     }
+    __syncthreads();
+    if (wave > wd && below) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k0 + k < T) {
+          const double cinv = R[k][0], sn = R[k][1], c = R[k][2];
+          const double ln = fma(sn, x, cur[k]) * cinv;
+          x = fma(c, x, -sn * ln);
+          cur[k] = ln;
+        }
+      }
+    }
+    if (below) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (k0 + j <= i) L[(size_t)i * T + k0 + j] = cur[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
   }
-  if (lane == 0 && a.info) a.info[m] = info;
+  if (info != 0 && lane == 0) {                 // the earliest bad pivot over the waves wins (a bad alpha/beta stays -1)
+    const int old = atomicCAS(&s_info, 0, info);
+    if (old > info) atomicMin(&s_info, info);
+  }
+  __syncthreads();
+  if (i == 0 && a.info) a.info[m] = s_info;
 }
 
 // a10 (reference as written, GPI.py:1043): || G^{-1} y ||^2 with G = tril(K) used as if it were a Cholesky factor.
@@ -1892,7 +1954,7 @@ int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const do
   if (b == 0) return 0;
   if (T > 256) return -2;
   Rank1Args a{L, v, alpha, beta, T, b, info};
-  hipLaunchKernelGGL(k_chol_rank1, dim3((b + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_chol_rank1, dim3(b), dim3(64 * ((T + 63) / 64)), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -48,3 +48,15 @@ for (S,T) in [(4096,128),(4096,90),(4096,64),(16384,90)]:
     Ss=(0.5*(Sig+Sig.transpose(1,2))).contiguous()
     t=timeit(lambda: ops.score_each(Y,mean,Ss,sm,symmetric=True))
     print(f"score_each(sym) S={S} T={T}: {t*1e3:.3f} ms -> {S/t:.3e} evals/s, {S*T*T*8/t/1e9:.1f} GB/s (algorithmic bytes)", flush=True)
+
+for (b, T) in [(16, 256), (1024, 256), (4096, 128), (4096, 90)]:
+    rng = np.random.default_rng(0)
+    Q = rng.normal(size=(8, T, T)); A = Q @ Q.transpose(0, 2, 1) / T + np.eye(T)
+    L = dev(np.tile(np.linalg.cholesky(A), (b // 8, 1, 1))); v = dev(rng.normal(size=(b, T)))
+    al = dev(np.full(b, 0.98)); be = dev(np.full(b, 0.5))
+    info = torch.zeros(b, dtype=torch.int32, device="cuda")
+    from hdpgpc_amd import _ffi
+    Lw = L.clone()
+    f = lambda: _ffi.check(_ffi.lib.hgp_chol_rank1_f64(ops._ptr(Lw), ops._ptr(v), ops._ptr(al), ops._ptr(be), T, b, ops._ptr(info), ops._stream()), "r1")
+    t = timeit(f, n=3, w=1)
+    print(f"chol_rank1 b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} updates/s, {b*T*T*8/t/1e9:.1f} GB/s (algorithmic: lower triangle in and out)", flush=True)
