@@ -78,12 +78,74 @@ def secondary_shared_grid(dev, ops, S=16384, T=90, reps=10):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
 
 
+def secondary_large_T(dev, ops, orc, N=1024, K=16, T=256, reps=3):
+    """BASELINE configs[3] shape on ONE GPU (a quarter of its 4 096 segments per GPU): 16 clusters, T = 256, irregular
+    grids - the cooperative pairs kernel (one workgroup per pair).  Same accounting as the headline: algorithmic
+    FLOPs T^3/3 + 3T^2 per eval against the fp64 MFMA peak."""
+    b = orc.synthetic_batch(N, K, T, seed=20260703)
+    d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
+    plan = ops.PairsPlan(T, T, b["theta"], device=dev)
+    xb, mean, Sig, x, y = d(b["xb"]), d(b["mean"]), d(b["Sigma"]), d(b["x"]), d(b["y"])
+    plan.update(xb, mean, Sig)
+    plan.loglik(x, y, want_logdet=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan.update(xb, mean, Sig)
+    e0.record()
+    for _ in range(reps):
+        quad, _, info = plan.loglik(x, y, want_logdet=False)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert int(info.abs().max()) == 0 and bool(torch.isfinite(quad).all())
+    ms = e0.elapsed_time(e1) / reps
+    tf = N * K * algorithmic_flops_per_eval(T) / (ms * 1e-3) / 1e12
+    return {"workload": f"configs[3] shape on one GPU: {N} segments x {K} clusters, T={T}, irregular grids (k_pairs_coop<16>)",
+            "value": N * K / dt, "unit": "evals/s", "ms_per_step": dt * 1e3, "kernel_ms": ms,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T)}}
+
+
+def secondary_rank1(dev, ops, b=1024, T=256, reps=5):
+    """BASELINE configs[4]'s kernel: L <- chol(alpha L L^T + beta v v^T) by a rank-1 update, batch of b factors, T = 256.
+    HBM-bound: 8 T^2 algorithmic bytes per update (the lower triangle in and out)."""
+    from hdpgpc_amd import _ffi
+    rng = np.random.default_rng(2)
+    Q = rng.normal(size=(8, T, T))
+    L0 = np.linalg.cholesky(Q @ Q.transpose(0, 2, 1) / T + np.eye(T))
+    L = torch.as_tensor(np.tile(L0, (b // 8, 1, 1)), dtype=torch.float64, device=dev)
+    v = torch.as_tensor(rng.normal(size=(b, T)), dtype=torch.float64, device=dev)
+    al = torch.full((b,), 0.98, dtype=torch.float64, device=dev)
+    be = torch.full((b,), 0.5, dtype=torch.float64, device=dev)
+    info = torch.zeros(b, dtype=torch.int32, device=dev)
+
+    def run():
+        _ffi.check(_ffi.lib.hgp_chol_rank1_f64(ops._ptr(L), ops._ptr(v), ops._ptr(al), ops._ptr(be), T, b, ops._ptr(info),
+                                               ops._stream()), "chol_rank1")
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    assert int(info.abs().max()) == 0
+    ms = e0.elapsed_time(e1) / reps
+    gbs = b * 8.0 * T * T / (ms * 1e-3) / 1e9
+    return {"workload": f"configs[4] kernel: rank-1 Cholesky update of {b} factors, T={T} (k_chol_rank1)",
+            "value": b / (ms * 1e-3), "unit": "updates/s", "kernel_ms": ms,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline workload only (used for the PMC passes)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on a one-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -178,8 +240,10 @@ def main():
                          # what the kernel actually issues (band-skipped): 1548 v_mfma_f64_16x16x4 of 2048 FLOP per pair
                          "executed_mfma_tflops": N_SEG * K_CL * 1548 * 2048 / (kern_ms * 1e-3) / 1e12},
         }
-        if world == 1:
+        if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_shared_grid(dev, ops)
+            res["secondary_large_T"] = secondary_large_T(dev, ops, orc)
+            res["secondary_rank1"] = secondary_rank1(dev, ops)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(batch)
         print(json.dumps(res), flush=True)

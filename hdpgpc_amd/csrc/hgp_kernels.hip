@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     pa.init();
     d4 Rnone[NB];
     HGP_ACC(4);
-    const double q = wave_factor<NB, 2>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
+    const double q = wave_factor<NB, 2, (NB >= 8)>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
     if (lane == 0) {
       a.out_quad[oidx] = q;
       if (a.out_logdet) a.out_logdet[oidx] = pa.logdet();
