@@ -125,3 +125,66 @@ def test_many_right_hand_sides_one_factor():
     assert int(info.abs().max()) == 0
     ref = -2.0 * (orc.gaussian_score_shared_cov(Y, mean, cov) + 0.5 * T * orc.LOG2PI)
     assert rel_err(quad.cpu().numpy(), ref) < 1e-10
+
+
+@pytest.mark.parametrize("T", [129, 177, 255])
+def test_large_sizes_that_are_not_multiples_of_the_tile(T):
+    """128 < T <= 256 goes through the cooperative kernels (one workgroup per matrix / per pair), padded to 192 / 256."""
+    b = orc.synthetic_batch(3, 2, T, seed=T)
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    quad, logdet, info = plan.loglik(dev(b["x"]), dev(b["y"]))
+    _, q_ref, ld_ref = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
+    assert int(info.abs().max()) == 0
+    assert rel_err(quad.cpu().numpy(), q_ref) < 1e-8 and rel_err(logdet.cpu().numpy(), ld_ref) < 1e-8
+
+
+def test_large_T_segment_grid_longer_and_shorter_than_the_basis():
+    """T* != T above 128 points: basis of 150 scored on 200-point segments (plan padded to 256) and on 100-point ones;
+    basis of 100 scored on 140-point segments (the segment side alone forces the cooperative kernel)."""
+    for T, Ts in ((150, 200), (150, 100), (100, 140)):
+        b = orc.synthetic_batch(3, 2, T, seed=T + Ts)
+        rng = np.random.default_rng(Ts)
+        x = np.sort(rng.uniform(0, T - 1, size=(3, Ts)), axis=1)
+        y = rng.normal(size=(3, Ts)) * 3
+        plan = ops.PairsPlan(T, Ts, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+        quad, logdet, info = plan.loglik(dev(x), dev(y))
+        _, q_ref, ld_ref = orc.loglik_pairs(x, y, b["xb"], b["theta"], b["mean"], b["Sigma"])
+        assert int(info.abs().max()) == 0
+        assert rel_err(quad.cpu().numpy(), q_ref) < 1e-8 and rel_err(logdet.cpu().numpy(), ld_ref) < 1e-8
+
+
+def test_large_T_mixed_lengthscales_iso_first_and_selection():
+    """Cooperative kernel with everything at once: two length-scale groups (one launch each), an iso-diagonal cluster
+    (GPI.py:497 short cut), per-pair `first` inflation and per-segment cluster selection."""
+    T, N, K = 144, 6, 4
+    b = orc.synthetic_batch(N, K, T, seed=12)
+    b["theta"][1, 1] = 0.9                                 # second length-scale group
+    b["theta"][3, 1] = 0.9
+    b["Sigma"][2] = 1.7 * np.eye(T)                        # iso branch
+    rng = np.random.default_rng(1)
+    fn = rng.uniform(0.0, 0.05, size=(N, K)) * (rng.uniform(size=(N, K)) < 0.5)
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    quad, logdet, info = plan.loglik(dev(b["x"]), dev(b["y"]), first_noise=dev(fn))
+    _, q_ref, ld_ref = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"], first_noise=fn)
+    assert int(info.abs().max()) == 0
+    assert rel_err(quad.cpu().numpy(), q_ref) < 1e-8 and rel_err(logdet.cpu().numpy(), ld_ref) < 1e-8
+    sel = np.array([0, 1, 2, 3, 1, 2])
+    q1, l1, i1 = plan.loglik(dev(b["x"]), dev(b["y"]), first_noise=dev(fn[np.arange(N), sel]),
+                             sel=torch.as_tensor(sel, dtype=torch.int32, device="cuda"))
+    assert int(i1.abs().max()) == 0
+    assert rel_err(q1.cpu().numpy(), q_ref[np.arange(N), sel]) < 1e-8
+    assert rel_err(l1.cpu().numpy(), ld_ref[np.arange(N), sel]) < 1e-8
+
+
+def test_large_T_not_positive_definite_is_reported_per_pair():
+    """A cluster whose Sigma makes cov_f indefinite: info > 0 for its pairs only, the other cluster's results are exact."""
+    T, N = 160, 3
+    b = orc.synthetic_batch(N, 2, T, seed=5)
+    Sig = b["Sigma"].copy()
+    Sig[1] = -50.0 * np.eye(T) + 0.1 * np.ones((T, T))      # not iso (off-diagonal), strongly negative
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(Sig))
+    quad, logdet, info = plan.loglik(dev(b["x"]), dev(b["y"]))
+    info = info.cpu().numpy()
+    assert (info[:, 0] == 0).all() and (info[:, 1] > 0).all()
+    _, q_ref, _ = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"][:1], b["mean"][:1], b["Sigma"][:1])
+    assert rel_err(quad[:, 0].cpu().numpy(), q_ref[:, 0]) < 1e-8
