@@ -34,20 +34,29 @@ def algorithmic_flops_per_eval(T):
     return T ** 3 / 3.0 + 3.0 * T ** 2
 
 
-def cpu_baseline(batch, budget_s=12.0):
-    """The oracle (NumPy/SciPy restatement of the reference's per-pair path) on the host cores, bounded sample."""
-    from oracle import hdpgpc_oracle as orc
-    t0 = time.perf_counter()
-    done = 0
-    n = 0
-    while time.perf_counter() - t0 < budget_s and n < batch["x"].shape[0]:
-        orc.loglik_pairs(batch["x"][n:n + 1], batch["y"][n:n + 1], batch["xb"], batch["theta"], batch["mean"], batch["Sigma"])
-        done += batch["theta"].shape[0]
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "evals/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
-            "sample": f"{done} evals ({n} segments x {batch['theta'].shape[0]} clusters, T={batch['x'].shape[1]}) "
-                      f"of the same workload in {dt:.1f} s; NumPy/SciPy oracle, BLAS threads = all host cores"}
+def cpu_baseline(budget_s=12.0):
+    """The oracle (NumPy/SciPy restatement of the reference's per-pair path) on the host cores, bounded sample: one
+    single-threaded worker process per core of this process's share (at most 16 - the one-GPU box's share), each
+    scoring its own slice of the SAME workload for `budget_s` seconds.  The rate is the sum of the workers' rates."""
+    import subprocess
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    per = N_SEG // cores
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", str(w * per), str((w + 1) * per), str(N_SEG),
+                               str(K_CL), str(T_LEN), "20260703", str(budget_s)], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for w in range(cores)]
+    done, rate = 0, 0.0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=budget_s + 120)
+            r = json.loads(out.strip().splitlines()[-1])
+            done += r["done"]
+            rate += r["done"] / r["dt"]
+        except Exception:                 # a worker that failed or overran contributes nothing
+            p.kill()
+    return {"value": rate, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{done} evals of the same workload (T={T_LEN}, {K_CL} clusters) in {budget_s:.0f} s on {cores} worker "
+                      f"processes, one BLAS thread each; NumPy/SciPy oracle"}
 
 
 def secondary_shared_grid(dev, ops, S=16384, T=90, reps=10):
@@ -245,7 +254,7 @@ def main():
             res["secondary_large_T"] = secondary_large_T(dev, ops, orc)
             res["secondary_rank1"] = secondary_rank1(dev, ops)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(batch)
+            res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
