@@ -288,7 +288,7 @@ class GPI_model:
             P = mm(mm(A, cov_prior), A, transB=True) + Gamma
             f_star, cov_f = mm(C, xm), Sigma                  # pred_dist short-circuits on the shared grid (GPI.py:467-468)
         S = mm(mm(C, P), C, transB=True) + cov_f
-        K_t = mm(mm(P, C, transB=True), self._spd_inv(0.5 * (S + S.T), "posterior"))          # P C^T S^{-1}  (GPI.py:144-145)
+        K_t = mm(mm(P, C, transB=True), self._spd_inv(S, "posterior"))   # P C^T S^{-1} (GPI.py:144-145); the inverse symmetrises on load
         mean_post = xm + mm(K_t, y - f_star)
         IKC = self._eye() - mm(K_t, C)
         cov_post = mm(mm(IKC, P), IKC, transB=True) + mm(mm(K_t, cov_f.contiguous()), K_t, transB=True)   # Joseph form
@@ -339,7 +339,7 @@ class GPI_model:
             A, Gam = self.A[-1], self.Gamma[-1]
             m0, m1, c0, c1 = self.f_star[-2], self.f_star[-1], self.cov_f[-2], self.cov_f[-1]
             P = mm(mm(A, c0), A, transB=True) + Gam
-            J = mm(mm(c0, A, transB=True), self._spd_inv(0.5 * (P + P.T), "backwards_pair"))     # c0 A^T P^{-1}
+            J = mm(mm(c0, A, transB=True), self._spd_inv(P, "backwards_pair"))     # c0 A^T P^{-1}; the inverse symmetrises on load
             self.f_star_sm[-2] = m0 + mm(J, m1 - mm(A, m0))
             self.cov_f_sm[-2] = c0 + mm(mm(J, c1 - P), J, transB=True)
             self.f_star_sm[-1], self.cov_f_sm[-1] = m1, c1
@@ -381,7 +381,7 @@ class GPI_model:
             A = A_list[t] if t < len(A_list) else A_list[-1]
             Gam = G_list[t] if t < len(G_list) else G_list[-1]
             P = mm(mm(A, covs[t]), A, transB=True) + Gam
-            J = mm(mm(covs[t], A, transB=True), self._spd_inv(0.5 * (P + P.T), "backwards"))
+            J = mm(mm(covs[t], A, transB=True), self._spd_inv(P, "backwards"))
             means[t] = means[t] + mm(J, means[t + 1] - mm(A, means[t]))
             covs[t] = covs[t] + mm(mm(J, covs[t + 1] - P), J, transB=True)
         for i in range(len(means)):
@@ -436,28 +436,45 @@ class GPI_model:
         return new_means, S__, new_scales, i1 + i2
 
     def _chain_step(self, ch, y):
-        """One member (N >= 2 after it): include_sample + backwards_pair + bayesian_new_params on the stacks."""
+        """One member (N >= 2 after it): include_sample + backwards_pair + bayesian_new_params on the stacks.
+
+        (Measured: running the three branches that only read the previous state - Kalman update, smoother gain, first
+        MNIW inverse - on separate streams, i.e. as parallel branches of the captured hipGraph, is SLOWER on ROCm 7.2:
+        1.03 ms instead of 0.77 ms per member.  One stream.)"""
         mm = ops.gemm_batched
         eye = self._eye()
         pos = ch["pos"]
         nxt = pos + 1
         sel = lambda k: ch[k].index_select(0, pos)[0]     # noqa: E731
         A, G, C, S = sel("A"), sel("G"), sel("C"), sel("S")
-        f_post, c_post = self._posterior(sel("Fsm"), sel("Psm"), y, A, G, C, S, False)
         m0, c0 = sel("F"), sel("P")                        # filtered values of the previous step
+        n0 = ch["n0"]
+        means, Rs, scales = torch.stack((ch["mi"], ch["mo"])), torch.stack((ch["Ri"], ch["Ro"])), torch.stack((ch["si"], ch["so"]))
+        f_post, c_post = self._posterior(sel("Fsm"), sel("Psm"), y, A, G, C, S, False)
         for k, v in (("F", f_post), ("Fsm", f_post), ("P", c_post), ("Psm", c_post)):
             ch[k].index_copy_(0, nxt, v.unsqueeze(0))
         # backwards_pair on the last two filtered states
         P = mm(mm(A, c0), A, transB=True) + G
-        J = mm(mm(c0, A, transB=True), self._spd_inv(0.5 * (P + P.T), "backwards_pair"))
-        f_sm_prev = m0 + mm(J, f_post - mm(A, m0))
+        J = mm(mm(c0, A, transB=True), self._spd_inv(P, "backwards_pair"))    # (the inverse symmetrises on load)
+        Am0 = mm(A, m0)
+        # the two MNIW updates (internal, observation) as one batch of 2
+        jit = 1e-2 * torch.clamp_min(torch.mean(torch.diagonal(scales, dim1=1, dim2=2).abs(), dim=1), np.finfo(np.float64).eps)
+        Z, i1 = ops.chol_inverse((Rs + jit.reshape(2, 1, 1) * eye).contiguous())
+        scale_inv = mm(Z, Z, transA=True)
+        m_si = mm(means.contiguous(), scale_inv)
+        f_sm_prev = m0 + mm(J, f_post - Am0)
         ch["Fsm"].index_copy_(0, pos, f_sm_prev.unsqueeze(0))
         ch["Psm"].index_copy_(0, pos, (c0 + mm(mm(J, c_post - P), J, transB=True)).unsqueeze(0))
         # bayesian_new_params (one-step MNIW update; on a failed factorisation the previous distributions are kept)
-        n0 = ch["n0"]
-        nm, nR, ns, binfo = self._mniw_post_dev2(torch.stack((ch["mi"], ch["mo"])), torch.stack((ch["Ri"], ch["Ro"])),
-                                                 torch.stack((ch["si"], ch["so"])), n0, torch.stack((f_post, y)),
-                                                 torch.stack((f_sm_prev, f_post)), eye)
+        y1s, y2s = torch.stack((f_post, y)), torch.stack((f_sm_prev, f_post))
+        S__ = mm(y2s, y2s, transB=True) + scale_inv
+        S_ = mm(y1s, y2s, transB=True) + m_si
+        Zs, i2 = ops.chol_inverse(S__.contiguous(), 0.0, 1e-8)
+        part = mm(mm(S_.contiguous(), Zs, transB=True), Zs)
+        nm = ((n0 - 2.0) * means + part) / (n0 - 1.0)
+        e = y1s - y2s
+        ns = ((n0 - 2.0) * scales + mm(e, e, transB=True)) / (n0 - 1.0)
+        nR, binfo = S__, i1 + i2
         bad = (binfo.sum() != 0).reshape(1)
         ch["bad"] += bad.to(torch.int32)
         for k, v in (("mi", nm[0]), ("Ri", nR[0]), ("si", ns[0]), ("mo", nm[1]), ("Ro", nR[1]), ("so", ns[1])):
@@ -534,7 +551,7 @@ class GPI_model:
             mt, ct = M.index_select(0, t)[0], Cv.index_select(0, t)[0]
             mn, cn = M.index_select(0, t + 1)[0], Cv.index_select(0, t + 1)[0]
             P = mm(mm(At, ct), At, transB=True) + Gt
-            J = mm(mm(ct, At, transB=True), self._spd_inv(0.5 * (P + P.T), "backwards"))
+            J = mm(mm(ct, At, transB=True), self._spd_inv(P, "backwards"))
             M.index_copy_(0, t, (mt + mm(J, mn - mm(At, mt))).unsqueeze(0))
             Cv.index_copy_(0, t, (ct + mm(mm(J, cn - P), J, transB=True)).unsqueeze(0))
             t.sub_(1)
