@@ -556,18 +556,28 @@ class GPI_model:
         Cv = torch.stack(self.cov_f[1:]).contiguous()
         A = torch.stack(self.A[1:]).contiguous()
         G = torch.stack(self.Gamma[1:]).contiguous()
-        nA = A.shape[0]
-        t = torch.tensor([M.shape[0] - 2], dtype=torch.int64, device=self.device)
+        nA, n = A.shape[0], M.shape[0]
+        # Everything that only reads the FILTERED states is batched over all steps at once (GPI.py:252-262 uses the
+        # filtered cov_t for P_t and the gain J_t): P_t = A_t c_t A_t^T + G_t, its inverse, J_t = c_t A_t^T P_t^{-1} and
+        # A_t m_t.  Only the two-line recursion itself stays sequential.
+        if nA >= n - 1:
+            Ab, Gb = A[:n - 1], G[:n - 1]
+        else:
+            ta_all = torch.clamp_max(torch.arange(n - 1, device=self.device), nA - 1)
+            Ab, Gb = A.index_select(0, ta_all), G.index_select(0, ta_all)
+        Pb = mm(mm(Ab, Cv[:n - 1]), Ab, transB=True) + Gb
+        Zb, infob = ops.chol_inverse(Pb)
+        self._pending.append(("backwards", infob))
+        Jb = mm(mm(Cv[:n - 1], Ab, transB=True), mm(Zb, Zb, transA=True))
+        AMb = mm(Ab, M[:n - 1])
+        t = torch.tensor([n - 2], dtype=torch.int64, device=self.device)
 
         def step():
-            ta = torch.clamp_max(t, nA - 1)
-            At, Gt = A.index_select(0, ta)[0], G.index_select(0, ta)[0]
+            Jt, Pt = Jb.index_select(0, t)[0], Pb.index_select(0, t)[0]
             mt, ct = M.index_select(0, t)[0], Cv.index_select(0, t)[0]
             mn, cn = M.index_select(0, t + 1)[0], Cv.index_select(0, t + 1)[0]
-            P = mm(mm(At, ct), At, transB=True) + Gt
-            J = mm(mm(ct, At, transB=True), self._spd_inv(P, "backwards"))
-            M.index_copy_(0, t, (mt + mm(J, mn - mm(At, mt))).unsqueeze(0))
-            Cv.index_copy_(0, t, (ct + mm(mm(J, cn - P), J, transB=True)).unsqueeze(0))
+            M.index_copy_(0, t, (mt + mm(Jt, mn - AMb.index_select(0, t)[0])).unsqueeze(0))
+            Cv.index_copy_(0, t, (ct + mm(mm(Jt, cn - Pt), Jt, transB=True)).unsqueeze(0))
             t.sub_(1)
 
         self._run_graphed(step, M.shape[0] - 1)
