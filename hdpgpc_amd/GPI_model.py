@@ -408,32 +408,19 @@ class GPI_model:
               "Psm": stack(self.cov_f_sm, (T, T)), "A": stack(self.A, (T, T)), "G": stack(self.Gamma, (T, T)),
               "C": stack(self.C, (T, T)), "S": stack(self.Sigma, (T, T))}
         ch["pos"] = torch.tensor([L - 1], dtype=torch.int64, device=dev)
-        ch["Nf"] = torch.tensor(float(self.N), dtype=f64, device=dev)
-        ch["n0"] = torch.tensor(float(self.internal_params.n0), dtype=f64, device=dev)
+        ch["Nf"] = torch.tensor([float(self.N)], dtype=f64, device=dev)
+        ch["n0"] = torch.tensor([float(self.internal_params.n0)], dtype=f64, device=dev)
         eye = self._eye()
-        for tag, mn in (("i", self.internal_params), ("o", self.observation_params)):
-            ch["m" + tag] = mn.m_mean.clone()
-            ch["R" + tag] = (eye if mn.m_r_cov is None else mn.m_r_cov).clone()
-            ch["s" + tag] = mn.scale.clone()
+        # the two MNIW distributions (internal, observation) as one tensor: W[0] = means, W[1] = right covariances,
+        # W[2] = scales, each [2,T,T]
+        mi, mo = self.internal_params, self.observation_params
+        ch["W"] = torch.stack((torch.stack((mi.m_mean, mo.m_mean)),
+                               torch.stack((eye if mi.m_r_cov is None else mi.m_r_cov, eye if mo.m_r_cov is None else mo.m_r_cov)),
+                               torch.stack((mi.scale, mo.scale)))).contiguous()
+        ch["ws"] = torch.empty(6 * T * T + 2 * T, dtype=f64, device=dev)     # gathered previous state (hgp_lds_chain_gather_f64)
+        ch["X4"] = torch.empty((4, T, T), dtype=f64, device=dev)             # input of the batched inverse of a step
         ch["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
         return ch
-
-    @staticmethod
-    def _mniw_post_dev2(means, Rs, scales, n0, y1s, y2s, eye):
-        """Two matrix_normal_inv_wishart.posterior updates (internal, observation) as ONE batch of 2: every operand is
-        [2,T,T] / [2,T,1]; n0 is a device scalar.  Returns (means', R', scales', info[2])."""
-        mm = ops.gemm_batched
-        jit = 1e-2 * torch.clamp_min(torch.mean(torch.diagonal(scales, dim1=1, dim2=2).abs(), dim=1), np.finfo(np.float64).eps)
-        Z, i1 = ops.chol_inverse((0.5 * (Rs + Rs.transpose(1, 2)) + jit.reshape(2, 1, 1) * eye).contiguous())
-        scale_inv = mm(Z, Z, transA=True)
-        S__ = mm(y2s, y2s, transB=True) + scale_inv
-        S_ = mm(y1s, y2s, transB=True) + mm(means.contiguous(), scale_inv)
-        Zs, i2 = ops.chol_inverse(S__.contiguous(), 0.0, 1e-8)
-        part = mm(mm(S_.contiguous(), Zs, transB=True), Zs)
-        new_means = ((n0 - 2.0) * means + part) / (n0 - 1.0)
-        e = y1s - y2s
-        new_scales = ((n0 - 2.0) * scales + mm(e, e, transB=True)) / (n0 - 1.0)
-        return new_means, S__, new_scales, i1 + i2
 
     def _chain_step(self, ch, y):
         """One member (N >= 2 after it): include_sample + backwards_pair + bayesian_new_params on the stacks.
@@ -443,67 +430,50 @@ class GPI_model:
         1.03 ms instead of 0.77 ms per member.  One stream.)"""
         mm = ops.gemm_batched
         eye = self._eye()
+        T = eye.shape[0]
+        tt = T * T
         pos = ch["pos"]
-        nxt = pos + 1
-        sel = lambda k: ch[k].index_select(0, pos)[0]     # noqa: E731
-        A, G, C, S = sel("A"), sel("G"), sel("C"), sel("S")
-        m0, c0 = sel("F"), sel("P")                        # filtered values of the previous step
+        ws = ops.lds_chain_gather(ch["A"], ch["G"], ch["C"], ch["S"], ch["P"], ch["Psm"], ch["F"], ch["Fsm"], pos, ch["ws"])
+        A, G, C, S, c0, Psm = (ws[i * tt:(i + 1) * tt].view(T, T) for i in range(6))
+        m0, Fsm = ws[6 * tt:6 * tt + T].view(T, 1), ws[6 * tt + T:].view(T, 1)   # filtered / smoothed mean of the previous step
         n0 = ch["n0"]
-        means, Rs, scales = torch.stack((ch["mi"], ch["mo"])), torch.stack((ch["Ri"], ch["Ro"])), torch.stack((ch["si"], ch["so"]))
+        means, Rs, scales = ch["W"][0], ch["W"][1], ch["W"][2]
         # The three factorisations that only need the previous state go out as ONE batch of 4 single-matrix inverses
         # (a 90 x 90 inverse is latency-bound: 50 us whether the launch carries one matrix or four): S of the Kalman
-        # update, A c0 A^T + G of backwards_pair, and the two MNIW scale matrices.
-        Psm = sel("Psm")
+        # update, A c0 A^T + G of backwards_pair, and the two MNIW scale matrices.  Additions ride in the GEMM epilogues.
+        X4 = ch["X4"]                                                        # [4,T,T] input of the batched inverse
         AP = mm(A, torch.stack((Psm, c0)))                                   # A P_sm and A c0 (A shared)
-        PP = mm(AP, A, transB=True) + G                                      # predictive covariances of both
-        Pk, P = PP[0], PP[1]
-        xm = mm(A, sel("Fsm"))
+        PP = mm(AP, A, transB=True, add=G)                                   # predictive covariances of both
+        Pk = PP[0]
+        X4[1].copy_(PP[1])
+        P = X4[1]
+        xm = mm(A, Fsm)
         f_pred = mm(C, xm)                                                   # pred_dist short-circuits on the shared grid
-        Sk = mm(mm(C, Pk), C, transB=True) + S
-        jit = 1e-2 * torch.clamp_min(torch.mean(torch.diagonal(scales, dim1=1, dim2=2).abs(), dim=1), np.finfo(np.float64).eps)
-        Z4, i4 = ops.chol_inverse(torch.cat((torch.stack((Sk, P)), Rs + jit.reshape(2, 1, 1) * eye)))
+        mm(mm(C, Pk), C, transB=True, add=S, out=X4[0])
+        ops.add_diag_mean(Rs, scales, 1e-2, out=X4[2:])
+        Z4, i4 = ops.chol_inverse(X4)
         self._pending.append(("posterior / backwards_pair", i4[:2]))
         inv4 = mm(Z4, Z4, transA=True)
         i1, scale_inv = i4[2:], inv4[2:]
         # Kalman update (GPI.py:140-151, Joseph form)
         K_t = mm(mm(Pk, C, transB=True), inv4[0])
-        f_post = xm + mm(K_t, y - f_pred)
-        IKC = eye - mm(K_t, C)
-        c_post = mm(mm(IKC, Pk), IKC, transB=True) + mm(mm(K_t, S.contiguous()), K_t, transB=True)
-        for k, v in (("F", f_post), ("Fsm", f_post), ("P", c_post), ("Psm", c_post)):
-            ch[k].index_copy_(0, nxt, v.unsqueeze(0))
+        f_post = mm(K_t, y - f_pred, add=xm)
+        IKC = mm(K_t, C, alpha=-1.0, add=eye)
+        c_post = mm(mm(K_t, S), K_t, transB=True, add=mm(mm(IKC, Pk), IKC, transB=True))
         # backwards_pair on the last two filtered states
         J = mm(mm(c0, A, transB=True), inv4[1])
-        Am0 = mm(A, m0)
-        m_si = mm(means.contiguous(), scale_inv)
-        f_sm_prev = m0 + mm(J, f_post - Am0)
-        ch["Fsm"].index_copy_(0, pos, f_sm_prev.unsqueeze(0))
-        ch["Psm"].index_copy_(0, pos, (c0 + mm(mm(J, c_post - P), J, transB=True)).unsqueeze(0))
+        f_sm_prev = mm(J, f_post - mm(A, m0), add=m0)
+        P_sm_prev = mm(mm(J, c_post - P), J, transB=True, add=c0)
+        ops.lds_chain_scatter(f_post, c_post, f_sm_prev, P_sm_prev, ch["F"], ch["Fsm"], ch["P"], ch["Psm"], pos)
         # bayesian_new_params (one-step MNIW update; on a failed factorisation the previous distributions are kept)
         y1s, y2s = torch.stack((f_post, y)), torch.stack((f_sm_prev, f_post))
-        S__ = mm(y2s, y2s, transB=True) + scale_inv
-        S_ = mm(y1s, y2s, transB=True) + m_si
-        Zs, i2 = ops.chol_inverse(S__.contiguous(), 0.0, 1e-8)
-        part = mm(mm(S_.contiguous(), Zs, transB=True), Zs)
-        nm = ((n0 - 2.0) * means + part) / (n0 - 1.0)
+        S__ = mm(y2s, y2s, transB=True, add=scale_inv)
+        S_ = mm(y1s, y2s, transB=True, add=mm(means, scale_inv))
+        Zs, i2 = ops.chol_inverse(S__, 0.0, 1e-8)
+        part = mm(mm(S_, Zs, transB=True), Zs)
         e = y1s - y2s
-        ns = ((n0 - 2.0) * scales + mm(e, e, transB=True)) / (n0 - 1.0)
-        nR, binfo = S__, i1 + i2
-        bad = (binfo.sum() != 0).reshape(1)
-        ch["bad"] += bad.to(torch.int32)
-        for k, v in (("mi", nm[0]), ("Ri", nR[0]), ("si", ns[0]), ("mo", nm[1]), ("Ro", nR[1]), ("so", ns[1])):
-            ch[k].copy_(torch.where(bad, ch[k], v))
-        n0_new = torch.where(bad[0], n0, n0 + 1.0)
-        Nf = ch["Nf"] + 1.0
-        scl = n0_new / (n0_new - 2.0)
-        ch["A"].index_copy_(0, nxt, ch["mi"].unsqueeze(0))
-        ch["C"].index_copy_(0, nxt, ch["mo"].unsqueeze(0))
-        ann = 1.0 / (Nf * Nf) if self.annealing else 0.0
-        ch["G"].index_copy_(0, nxt, (ch["si"] * scl + ch["G"][0] * ann).unsqueeze(0))
-        ch["S"].index_copy_(0, nxt, (ch["so"] * scl + ch["S"][0] * ann).unsqueeze(0))
-        ch["n0"].copy_(n0_new)
-        ch["Nf"].copy_(Nf)
-        ch["pos"].add_(1)
+        ops.lds_chain_finish(part, mm(e, e, transB=True), S__, i1, i2, ch["W"], n0, ch["Nf"], ch["bad"], ch["A"], ch["G"],
+                             ch["C"], ch["S"], pos, self.annealing)
 
     def _chain_commit(self, ch, members, x_trains, y_trains):
         L = int(ch["pos"][0]) + 1
@@ -511,8 +481,9 @@ class GPI_model:
         self.f_star, self.f_star_sm, self.cov_f, self.cov_f_sm = unb("F"), unb("Fsm"), unb("P"), unb("Psm")
         self.A, self.Gamma, self.C, self.Sigma = unb("A"), unb("G"), unb("C"), unb("S")
         n0 = float(ch["n0"])
-        self.internal_params = matrix_normal_inv_wishart(ch["mi"], ch["Ri"], n0, ch["si"])
-        self.observation_params = matrix_normal_inv_wishart(ch["mo"], ch["Ro"], n0, ch["so"])
+        W = ch["W"]
+        self.internal_params = matrix_normal_inv_wishart(W[0, 0], W[1, 0], n0, W[2, 0])
+        self.observation_params = matrix_normal_inv_wishart(W[0, 1], W[1, 1], n0, W[2, 1])
         for idx in members:
             self.indexes.append(int(idx))
             self.x_train.append(x_trains[idx])

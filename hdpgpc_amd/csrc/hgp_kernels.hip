@@ -484,8 +484,14 @@ struct GemmArgs {
   int tA, tB;
   int nb2 = 1;                 // optional second batch level: item b = b1 * nb2 + b2 uses offsets b1 * s?  + b2 * s?2
   long sA2 = 0, sB2 = 0, sC2 = 0;
+  const double* D = nullptr;   // optional addend (instead of C): C = alpha op(A) op(B) + beta D
+  int ldd = 0;
+  long sD = 0;
 };
 
+// TRIP = k-steps whose operand loads are issued before the first MFMA of a trip.  TRIP = 24 covers Kd <= 96 in ONE
+// trip (the LDS recursion's 90 x 90 products: one load latency instead of three per tile).
+template <int TRIP>
 __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
@@ -500,10 +506,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
   const int row = 16 * ti + c, col = 16 * tj + c;
   const int nk = (a.Kd + 3) / 4;
-  for (int k0 = 0; k0 < nk; k0 += 8) {   // 8 k-steps per trip: their 16 operand loads are issued before the first MFMA
-    double av[8], bv[8];
+  for (int k0 = 0; k0 < nk; k0 += TRIP) {   // TRIP k-steps per trip: their 2 TRIP operand loads are issued before the first MFMA
+    double av[TRIP], bv[TRIP];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < TRIP; ++u) {
       const int k = 4 * (k0 + u) + g;
       av[u] = 0.0;
       bv[u] = 0.0;
@@ -513,14 +519,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = mfma(av[u], bv[u], acc);
+    for (int u = 0; u < TRIP; ++u) acc = mfma(av[u], bv[u], acc);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 16 * ti + g + 4 * r;
     if (i < a.M && col < a.N) {
       double v = a.alpha * acc[r];
-      if (a.beta != 0.0) v += a.beta * C[(size_t)i * a.ldc + col];
+      if (a.beta != 0.0)
+        v += a.beta * (a.D ? a.D[(size_t)b1 * a.sD + (size_t)i * a.ldd + col] : C[(size_t)i * a.ldc + col]);
       C[(size_t)i * a.ldc + col] = v;
     }
   }
@@ -528,7 +535,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
 
 int launch_gemm(const GemmArgs& a, int batch, hipStream_t st) {
   const int nt = ((a.M + 15) / 16) * ((a.N + 15) / 16);
-  hipLaunchKernelGGL(k_gemm, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
+  if (a.Kd <= 96 && a.Kd > 32)
+    hipLaunchKernelGGL(k_gemm<24>, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_gemm<8>, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
   return launch_status();
 }
 
@@ -697,6 +707,143 @@ __global__ __launch_bounds__(256) void k_chol_rank1(Rank1Args a) {
   __syncthreads();
   if (i == 0 && a.info) a.info[m] = s_info;
 }
+
+// ------------------------------------------------------------------ 8f-1: glue of the LDS chain step, fused
+// The captured per-member step (hdpgpc_amd/GPI_model.py: _chain_step) is a chain of small GEMMs and inverses; what sits
+// between them was ~75 element-wise / index launches of 3-5 us each.  Two kernels replace most of them.
+//
+// k_chain_gather: rows `pos` of the eight state stacks -> one contiguous workspace (A, G, C, S, P, Psm [T,T]; F, Fsm [T]).
+struct ChainGatherArgs {
+  const double* st[8];   // A, G, C, S, P, Psm (T*T each), F, Fsm (T each)
+  const int64_t* pos;
+  double* out;           // [6 T T + 2 T]
+  int T;
+};
+
+__global__ __launch_bounds__(256) void k_chain_gather(ChainGatherArgs a) {
+  const long tt = (long)a.T * a.T, p = a.pos[0];
+  const long total = 6 * tt + 2 * a.T;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    double v;
+    if (i < 6 * tt) {
+      const int w = (int)(i / tt);
+      v = a.st[w][p * tt + (i - w * tt)];
+    } else {
+      const long j = i - 6 * tt;
+      const int w = 6 + (int)(j / a.T);
+      v = a.st[w][p * a.T + (j - (long)(w - 6) * a.T)];
+    }
+    a.out[i] = v;
+  }
+}
+
+// k_chain_scatter: the new filtered state and the re-smoothed previous one into the stacks (rows pos + 1 and pos).
+struct ChainScatterArgs {
+  const double* f_post;     // [T]
+  const double* c_post;     // [T,T]
+  const double* f_sm_prev;  // [T]
+  const double* P_sm_prev;  // [T,T]
+  double* stF;
+  double* stFsm;
+  double* stP;
+  double* stPsm;
+  const int64_t* pos;
+  int T;
+};
+
+__global__ __launch_bounds__(256) void k_chain_scatter(ChainScatterArgs a) {
+  const long tt = (long)a.T * a.T, p = a.pos[0], nx = p + 1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tt; i += (long)gridDim.x * 256) {
+    const double c = a.c_post[i];
+    a.stP[nx * tt + i] = c;
+    a.stPsm[nx * tt + i] = c;
+    a.stPsm[p * tt + i] = a.P_sm_prev[i];
+    if (i < a.T) {
+      const double f = a.f_post[i];
+      a.stF[nx * a.T + i] = f;
+      a.stFsm[nx * a.T + i] = f;
+      a.stFsm[p * a.T + i] = a.f_sm_prev[i];
+    }
+  }
+}
+
+// out[b] = R[b] + factor * max(mean |diag S[b]|, eps) I   (the jitter of matrix_normal_inv_wishart.posterior,
+// GPI_model.py:1312-1316, taken from the CURRENT scale matrix)
+__global__ __launch_bounds__(256) void k_add_diag_mean(const double* __restrict__ R, const double* __restrict__ S, int T,
+                                                       double factor, double* __restrict__ out) {
+  __shared__ double red[256];
+  const long tt = (long)T * T;
+  const double* Sb = S + (size_t)blockIdx.x * tt;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < T; i += 256) s += fabs(Sb[(size_t)i * T + i]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double jit = factor * fmax(red[0] / T, F64_EPS);
+  const double* Rb = R + (size_t)blockIdx.x * tt;
+  double* ob = out + (size_t)blockIdx.x * tt;
+  for (long i = threadIdx.x; i < tt; i += 256) ob[i] = Rb[i] + ((i / T == i % T) ? jit : 0.0);
+}
+
+// k_chain_finish: matrix_normal_inv_wishart.posterior's element-wise tail for BOTH updates (GPI_model.py:1326-1336),
+// the keep-previous rule on a failed factorisation (GPI_model.py:1068-1071), the annealed scales
+// (GPI_model.py:1083-1091), the append of A, Gamma, C, Sigma and the counters - one workgroup, one launch.
+struct ChainFinishArgs {
+  int T;
+  const double* part;     // [2,T,T]  S_ S__^{-1}
+  const double* ee;       // [2,T,T]  (y1 - y2)(y1 - y2)^T
+  const double* Snew;     // [2,T,T]  S__ (the new right covariance)
+  const int32_t* info1;   // [2]
+  const int32_t* info2;   // [2]
+  double* W;              // [3,2,T,T] means, R, scales (in/out)
+  double* n0;             // device scalars (in/out)
+  double* Nf;
+  int32_t* bad_count;
+  double* stA;            // stacks [L,T,T]: row pos + 1 is written
+  double* stG;
+  double* stC;
+  double* stS;
+  int64_t* pos;           // in/out: += 1
+  int annealing;
+};
+
+#pragma clang fp contract(off)   // the reference's op order, no fused multiply-adds
+__global__ __launch_bounds__(1024) void k_chain_finish(ChainFinishArgs a) {
+  const long tt = (long)a.T * a.T;
+  const bool bad = (a.info1[0] | a.info1[1] | a.info2[0] | a.info2[1]) != 0;
+  const double n0 = a.n0[0], Nf = a.Nf[0] + 1.0;
+  const long nxt = a.pos[0] + 1;
+  const double n0n = bad ? n0 : n0 + 1.0;
+  const double scl = n0n / (n0n - 2.0);
+  const double ann = a.annealing ? 1.0 / (Nf * Nf) : 0.0;
+  __syncthreads();   // every thread has read the scalars before thread 0 rewrites them below
+  for (long i = threadIdx.x; i < 2 * tt; i += 1024) {
+    double m = a.W[i], r = a.W[2 * tt + i], sc = a.W[4 * tt + i];
+    if (!bad) {
+      m = ((n0 - 2.0) * m + a.part[i]) / (n0 - 1.0);
+      r = a.Snew[i];
+      sc = ((n0 - 2.0) * sc + a.ee[i]) / (n0 - 1.0);
+      a.W[i] = m;
+      a.W[2 * tt + i] = r;
+      a.W[4 * tt + i] = sc;
+    }
+    const bool obs = i >= tt;           // item 0 = internal (A, Gamma), item 1 = observation (C, Sigma)
+    const long e = obs ? i - tt : i;
+    (obs ? a.stC : a.stA)[nxt * tt + e] = m;
+    double* sg = obs ? a.stS : a.stG;
+    sg[nxt * tt + e] = sc * scl + sg[e] * ann;
+  }
+  if (threadIdx.x == 0) {
+    a.n0[0] = n0n;
+    a.Nf[0] = Nf;
+    a.bad_count[0] += bad ? 1 : 0;
+    a.pos[0] = nxt;
+  }
+}
+#pragma clang fp contract(on)
 
 // a10 (reference as written, GPI.py:1043): || G^{-1} y ||^2 with G = tril(K) used as if it were a Cholesky factor.
 // One workgroup, column-oriented forward substitution in LDS; T <= 2048.
@@ -1577,7 +1724,7 @@ int launch_pairs_coop(const PairsArgs& a, hipStream_t st) {
   const size_t lds = PairsCoop<NB>::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs_coop<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs_coop<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int blocks = a.sel ? a.N : a.N * (a.kend - a.kbeg);
@@ -1590,7 +1737,7 @@ int launch_pairs(const PairsArgs& a, hipStream_t st) {
   size_t lds = pairs_lds_bytes<NB>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL(k_pairs<NB>, dim3(a.N), dim3(64 * WAVES), lds, st, a);
@@ -1955,6 +2102,54 @@ int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const do
   if (T > 256) return -2;
   Rank1Args a{L, v, alpha, beta, T, b, info};
   hipLaunchKernelGGL(k_chol_rank1, dim3(b), dim3(64 * ((T + 63) / 64)), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int hgp_lds_chain_gather_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stP,
+                             const double* stPsm, const double* stF, const double* stFsm, const int64_t* pos, int T,
+                             double* out, void* stream) {
+  if (!stA || !stG || !stC || !stS || !stP || !stPsm || !stF || !stFsm || !pos || !out || T <= 0) return -1;
+  ChainGatherArgs a{{stA, stG, stC, stS, stP, stPsm, stF, stFsm}, pos, out, T};
+  const long total = 6L * T * T + 2L * T;
+  hipLaunchKernelGGL(k_chain_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int hgp_lds_chain_scatter_f64(const double* f_post, const double* c_post, const double* f_sm_prev, const double* P_sm_prev,
+                              double* stF, double* stFsm, double* stP, double* stPsm, const int64_t* pos, int T, void* stream) {
+  if (!f_post || !c_post || !f_sm_prev || !P_sm_prev || !stF || !stFsm || !stP || !stPsm || !pos || T <= 0) return -1;
+  ChainScatterArgs a{f_post, c_post, f_sm_prev, P_sm_prev, stF, stFsm, stP, stPsm, pos, T};
+  hipLaunchKernelGGL(k_chain_scatter, dim3((unsigned)(((long)T * T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int hgp_add_diag_mean_f64(const double* R, const double* S, int T, int b, double factor, double* out, void* stream) {
+  if (!R || !S || !out || T <= 0 || b < 0) return -1;
+  if (b == 0) return 0;
+  hipLaunchKernelGGL(k_add_diag_mean, dim3(b), dim3(256), 0, (hipStream_t)stream, R, S, T, factor, out);
+  return launch_status();
+}
+
+int hgp_gemm_add_batched_f64(int transA, int transB, int M, int N, int Kd, double alpha, const double* A, int lda, long strideA,
+                             const double* B, int ldb, long strideB, double beta, const double* D, int ldd, long strideD,
+                             double* C, int ldc, long strideC, int batch, void* stream) {
+  if (!A || !B || !C || !D || M <= 0 || N <= 0 || Kd <= 0 || batch < 0) return -1;
+  if (batch == 0) return 0;
+  GemmArgs g{A, B, C, M, N, Kd, lda, ldb, ldc, strideA, strideB, strideC, alpha, beta, transA, transB};
+  g.D = D;
+  g.ldd = ldd;
+  g.sD = strideD;
+  return launch_gemm(g, batch, (hipStream_t)stream);
+}
+
+int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const double* Snew, const int32_t* info1,
+                             const int32_t* info2, double* W, double* n0, double* Nf, int32_t* bad_count, double* stA,
+                             double* stG, double* stC, double* stS, int64_t* pos, int annealing, void* stream) {
+  if (!part || !ee || !Snew || !info1 || !info2 || !W || !n0 || !Nf || !bad_count || !stA || !stG || !stC || !stS || !pos ||
+      T <= 0)
+    return -1;
+  ChainFinishArgs a{T, part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing};
+  hipLaunchKernelGGL(k_chain_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -234,8 +234,10 @@ class PairsPlan:
             pass
 
 
-def gemm_batched(A, B, transA=False, transB=False, alpha=1.0):
-    """C[b] = alpha op(A[b]) op(B[b]) on v_mfma_f64_16x16x4_f64; A [b,m,k] (or [m,k]), B [b,k,n] (or [k,n])."""
+def gemm_batched(A, B, transA=False, transB=False, alpha=1.0, add=None, beta=1.0, out=None):
+    """C[b] = alpha op(A[b]) op(B[b]) (+ beta add[b]) on v_mfma_f64_16x16x4_f64; A [b,m,k] (or [m,k]), B [b,k,n] (or [k,n]).
+    add: optional [m,n] (shared by the batch) or [b,m,n] addend fused into the epilogue; out: optional preallocated
+    contiguous [b,m,n] (or [m,n]) result."""
     A = _dev64(A, "A")
     B = _dev64(B, "B")
     a3 = A if A.dim() == 3 else A.unsqueeze(0)
@@ -245,10 +247,44 @@ def gemm_batched(A, B, transA=False, transB=False, alpha=1.0):
     N = b3.shape[1] if transB else b3.shape[2]
     sA = 0 if a3.shape[0] == 1 else a3.shape[1] * a3.shape[2]
     sB = 0 if b3.shape[0] == 1 else b3.shape[1] * b3.shape[2]
-    C = torch.empty((batch, M, N), dtype=torch.float64, device=A.device)
-    _ffi.check(_ffi.lib.hgp_gemm_batched_f64(int(transA), int(transB), M, N, Kd, alpha, _ptr(a3), a3.shape[2], sA, _ptr(b3),
-                                             b3.shape[2], sB, 0.0, _ptr(C), N, M * N, batch, _stream()), "gemm_batched")
+    if out is None:
+        C = torch.empty((batch, M, N), dtype=torch.float64, device=A.device)
+    else:
+        C = out if out.dim() == 3 else out.unsqueeze(0)
+        if tuple(C.shape) != (batch, M, N) or not C.is_contiguous() or C.dtype != torch.float64:
+            raise ValueError("gemm_batched: out must be a contiguous float64 [batch, M, N]")
+    if add is None:
+        _ffi.check(_ffi.lib.hgp_gemm_batched_f64(int(transA), int(transB), M, N, Kd, alpha, _ptr(a3), a3.shape[2], sA, _ptr(b3),
+                                                 b3.shape[2], sB, 0.0, _ptr(C), N, M * N, batch, _stream()), "gemm_batched")
+    else:
+        D = _dev64(add, "add")
+        d3 = D if D.dim() == 3 else D.unsqueeze(0)
+        if tuple(d3.shape[1:]) != (M, N) or d3.shape[0] not in (1, batch):
+            raise ValueError("gemm_batched: add must be [M, N] or [batch, M, N]")
+        sD = 0 if d3.shape[0] == 1 else M * N
+        _ffi.check(_ffi.lib.hgp_gemm_add_batched_f64(int(transA), int(transB), M, N, Kd, alpha, _ptr(a3), a3.shape[2], sA, _ptr(b3),
+                                                     b3.shape[2], sB, beta, _ptr(d3), N, sD, _ptr(C), N, M * N, batch, _stream()),
+                   "gemm_add_batched")
+    if out is not None:
+        return out
     return C if (A.dim() == 3 or B.dim() == 3) else C[0]
+
+
+def add_diag_mean(R, S, factor, out=None):
+    """out[b] = R[b] + factor * max(mean |diag S[b]|, eps) I  for [b,T,T] stacks (MNIW jitter, GPI_model.py:1312-1316)."""
+    R, S = _dev64(R, "R"), _dev64(S, "S")
+    b, T, _ = R.shape
+    if out is None:
+        out = torch.empty_like(R)
+    _ffi.check(_ffi.lib.hgp_add_diag_mean_f64(_ptr(R), _ptr(S), T, b, float(factor), _ptr(out), _stream()), "add_diag_mean")
+    return out
+
+
+def lds_chain_scatter(f_post, c_post, f_sm_prev, P_sm_prev, stF, stFsm, stP, stPsm, pos):
+    """8f-1 glue: append the new filtered state (rows pos + 1) and overwrite the re-smoothed previous one (rows pos)."""
+    T = stP.shape[1]
+    _ffi.check(_ffi.lib.hgp_lds_chain_scatter_f64(_ptr(f_post), _ptr(c_post), _ptr(f_sm_prev), _ptr(P_sm_prev), _ptr(stF),
+                                                  _ptr(stFsm), _ptr(stP), _ptr(stPsm), _ptr(pos), T, _stream()), "lds_chain_scatter")
 
 
 def lat_error(f_cur, f_prev, A, Gamma, covprev):
@@ -301,6 +337,22 @@ def chol_rank1(L, v, alpha=None, beta=None):
     info = torch.zeros(b, dtype=torch.int32, device=L.device)
     _ffi.check(_ffi.lib.hgp_chol_rank1_f64(_ptr(L3), _ptr(v), _ptr(al), _ptr(be), T, b, _ptr(info), _stream()), "chol_rank1")
     return (L3 if L.dim() == 3 else L3[0]), info
+
+
+def lds_chain_gather(stA, stG, stC, stS, stP, stPsm, stF, stFsm, pos, out):
+    """8f-1 glue: row pos[0] of the eight state stacks -> out[6 T T + 2 T] (A, G, C, S, P, Psm, F, Fsm)."""
+    T = stA.shape[1]
+    _ffi.check(_ffi.lib.hgp_lds_chain_gather_f64(_ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(stP), _ptr(stPsm), _ptr(stF),
+                                                 _ptr(stFsm), _ptr(pos), T, _ptr(out), _stream()), "lds_chain_gather")
+    return out
+
+
+def lds_chain_finish(part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing):
+    """8f-1 glue: element-wise tail of the two MNIW updates + append of A, Gamma, C, Sigma + counters (see the header)."""
+    T = stA.shape[1]
+    _ffi.check(_ffi.lib.hgp_lds_chain_finish_f64(T, _ptr(part), _ptr(ee), _ptr(Snew), _ptr(info1), _ptr(info2), _ptr(W), _ptr(n0),
+                                                 _ptr(Nf), _ptr(bad_count), _ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(pos),
+                                                 int(bool(annealing)), _stream()), "lds_chain_finish")
 
 
 def trsv_lower_quad(G, y):

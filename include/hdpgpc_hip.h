@@ -155,6 +155,37 @@ int hgp_warp_cov_f64(const double* x, int T, double rho, double omega, double di
 int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const double* beta, int T, int b, int32_t* info,
                        void* stream);
 
+/* 8f-1 (first "next" row) - glue of one member step of the LDS recursion (GPI_model.full_pass_weighted,
+ * GPI_model.py:377-406), fused so that a captured step is GEMMs + inverses + two of these launches.
+ * hgp_lds_chain_gather_f64: row pos[0] of the state stacks A, Gamma, C, Sigma, cov_f, cov_f_sm ([L,T,T]) and f_star,
+ *   f_star_sm ([L,T]) into out[6 T T + 2 T] in that order (replaces the per-step list indexing of GPI_model.py:300-318).
+ * hgp_lds_chain_finish_f64: element-wise tail of the two matrix_normal_inv_wishart.posterior updates
+ *   (GPI_model.py:1326-1336; item 0 = internal (A, Gamma), item 1 = observation (C, Sigma)):
+ *     bad = any(info1, info2 != 0)                      (then the previous distributions are kept, GPI_model.py:1068-1071)
+ *     means' = ((n0 - 2) means + part) / (n0 - 1);  R' = Snew;  scales' = ((n0 - 2) scales + ee) / (n0 - 1)
+ *     n0' = n0 + 1 (unless bad);  Nf' = Nf + 1;  scl = n0' / (n0' - 2);  ann = annealing ? 1 / Nf'^2 : 0
+ *     A[pos+1] = means'[0]; C[pos+1] = means'[1]; Gamma[pos+1] = scales'[0] scl + Gamma[0] ann; Sigma likewise
+ *                                                        (bayesian_new_params, GPI_model.py:1076-1106)
+ *     W = (means', R', scales') [3,2,T,T];  n0, Nf, bad_count, pos updated in place (pos += 1). */
+int hgp_lds_chain_gather_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stP,
+                             const double* stPsm, const double* stF, const double* stFsm, const int64_t* pos, int T,
+                             double* out, void* stream);
+/* hgp_lds_chain_scatter_f64: f_star[pos+1] = f_star_sm[pos+1] = f_post; cov_f[pos+1] = cov_f_sm[pos+1] = c_post
+ *   (include_sample, GPI_model.py:317); f_star_sm[pos] = f_sm_prev, cov_f_sm[pos] = P_sm_prev (backwards_pair,
+ *   GPI_model.py:705-716). */
+int hgp_lds_chain_scatter_f64(const double* f_post, const double* c_post, const double* f_sm_prev, const double* P_sm_prev,
+                              double* stF, double* stFsm, double* stP, double* stPsm, const int64_t* pos, int T, void* stream);
+/* out[b] = R[b] + factor * max(mean |diag S[b]|, eps) I  - the jitter matrix_normal_inv_wishart.posterior adds to the
+ * right covariance before inverting it (GPI_model.py:1312-1316). */
+int hgp_add_diag_mean_f64(const double* R, const double* S, int T, int b, double factor, double* out, void* stream);
+/* C[b] = alpha op(A[b]) op(B[b]) + beta D[b]  (D: leading dimension ldd, batch stride strideD, 0 = shared). */
+int hgp_gemm_add_batched_f64(int transA, int transB, int M, int N, int Kd, double alpha, const double* A, int lda, long strideA,
+                             const double* B, int ldb, long strideB, double beta, const double* D, int ldd, long strideD,
+                             double* C, int ldc, long strideC, int batch, void* stream);
+int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const double* Snew, const int32_t* info1,
+                             const int32_t* info2, double* W, double* n0, double* Nf, int32_t* bad_count, double* stA,
+                             double* stG, double* stC, double* stS, int64_t* pos, int annealing, void* stream);
+
 /* a10 helper - || G^{-1} y ||^2 for the lower triangle G of a [T, ld] matrix.  IterativeGaussianProcess.
  * log_marginal_likelihood as written passes K itself as the "factor" to cho_solve (GPI.py:1043); this reproduces
  * that call with G = tril(K).  out[1]. */
