@@ -420,6 +420,7 @@ class GPI_model:
         ch["ws"] = torch.empty(6 * T * T + 2 * T, dtype=f64, device=dev)     # gathered previous state (hgp_lds_chain_gather_f64)
         ch["X4"] = torch.empty((4, T, T), dtype=f64, device=dev)             # input of the batched inverse of a step
         ch["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        ch["sync"] = torch.zeros(1, dtype=torch.int32, device=dev)           # inter-block counter of hgp_lds_chain_finish_f64
         return ch
 
     def _chain_step(self, ch, y):
@@ -473,7 +474,7 @@ class GPI_model:
         part = mm(mm(S_, Zs, transB=True), Zs)
         e = y1s - y2s
         ops.lds_chain_finish(part, mm(e, e, transB=True), S__, i1, i2, ch["W"], n0, ch["Nf"], ch["bad"], ch["A"], ch["G"],
-                             ch["C"], ch["S"], pos, self.annealing)
+                             ch["C"], ch["S"], pos, self.annealing, ch["sync"])
 
     def _chain_commit(self, ch, members, x_trains, y_trains):
         L = int(ch["pos"][0]) + 1
@@ -541,6 +542,15 @@ class GPI_model:
         self._pending.append(("backwards", infob))
         Jb = mm(mm(Cv[:n - 1], Ab, transB=True), mm(Zb, Zb, transA=True))
         AMb = mm(Ab, M[:n - 1])
+        if M.shape[1] <= 96:          # the whole recursion in one launch (one workgroup walks the chain)
+            self._check_pending()
+            Mv = M.reshape(n, -1)
+            ops.rts_chain(Jb, Pb, AMb.reshape(n - 1, -1).contiguous(), Mv, Cv)
+            for i in range(n):
+                self.f_star_sm[i + 1] = M[i]
+                self.cov_f_sm[i + 1] = Cv[i]
+            self._stk = {}
+            return
         t = torch.tensor([n - 2], dtype=torch.int64, device=self.device)
 
         def step():

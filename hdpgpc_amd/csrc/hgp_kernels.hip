@@ -788,6 +788,130 @@ __global__ __launch_bounds__(256) void k_add_diag_mean(const double* __restrict_
   for (long i = threadIdx.x; i < tt; i += 256) ob[i] = Rb[i] + ((i / T == i % T) ? jit : 0.0);
 }
 
+// k_rts_chain: the sequential part of the RTS smoother (GPI.backward, GPI.py:240-270) for ALL steps in one launch.
+// The gains J_t, the predictive covariances P_t and A_t m_t only depend on the filtered states and are batched by the
+// caller; what remains is, for t = n-2 .. 0:
+//     m_t <- m_t + J_t (m_{t+1} - A_t m_t),      C_t <- C_t + J_t (C_{t+1} - P_t) J_t^T.
+// One workgroup walks the chain: J_t and D = C_{t+1} - P_t are staged in LDS (row pitch 100 doubles), X = J D is
+// formed tile-wise on the matrix core (each wave 9 of the 36 tiles, kept in registers until D is dead, then written
+// over it), then C_t + X J^T.  T <= 96.  C_{t+1} and m_{t+1} were written by the previous iteration of this same
+// workgroup: they are re-read with agent-scope loads behind a fence + barrier.
+struct RtsArgs {
+  const double* J;    // [n-1,T,T]
+  const double* P;    // [n-1,T,T]
+  const double* AM;   // [n-1,T]
+  double* M;          // [n,T]   in/out
+  double* Cv;         // [n,T,T] in/out
+  int n, T;
+};
+
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int RTS_WAVES = 12;   // three waves per SIMD: the LDS operand latency of one hides under the MFMAs of the others
+
+__global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
+  constexpr int NBR = 6, PITCH = 100;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Jl = smem;                    // [96][PITCH]
+  double* Dl = Jl + 96 * PITCH;         // [96][PITCH]  D, then X
+  double* vl = Dl + 96 * PITCH;         // [96]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.T;
+  const long tt = (long)T * T;
+  for (int i = tid; i < 96 * PITCH; i += 64 * RTS_WAVES) {   // zero padding once (rows/cols >= T are never written below)
+    Jl[i] = 0.0;
+    Dl[i] = 0.0;
+  }
+  if (tid < 96) vl[tid] = 0.0;
+  __syncthreads();
+  for (int t = a.n - 2; t >= 0; --t) {
+    const double* Jt = a.J + (size_t)t * tt;
+    const double* Pt = a.P + (size_t)t * tt;
+    const double* Cn = a.Cv + (size_t)(t + 1) * tt;
+    double* Ct = a.Cv + (size_t)t * tt;
+    // staging: wave w takes rows w, w + 12, ...; a lane covers columns lane and lane + 64.  Four rows (24 loads per
+    // lane) are in flight at once - the plain strided loop serialised one load latency per element.
+#pragma unroll 1
+    for (int r0 = wave; r0 < T; r0 += 4 * RTS_WAVES) {
+      double jv[4][2], cv[4][2], pv[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + RTS_WAVES * u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = lane + 64 * h;
+          const bool ok = r < T && q < T;
+          const long i = (long)r * T + q;
+          jv[u][h] = ok ? Jt[i] : 0.0;
+          pv[u][h] = ok ? Pt[i] : 0.0;
+          cv[u][h] = ok ? ld_agent(Cn + i) : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + RTS_WAVES * u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = lane + 64 * h;
+          if (r < T && q < T) {
+            Jl[r * PITCH + q] = jv[u][h];
+            Dl[r * PITCH + q] = cv[u][h] - pv[u][h];
+          }
+        }
+      }
+    }
+    if (tid < T) vl[tid] = ld_agent(a.M + (size_t)(t + 1) * T + tid) - a.AM[(size_t)t * T + tid];
+    __syncthreads();
+    // X = J D : tile (I, Jc) = wave + 12 i
+    d4 X[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int k = 0; k < 96; k += 4) acc = mfma(Jl[(16 * I + c) * PITCH + k + g], Dl[(k + g) * PITCH + 16 * Jc + c], acc);
+      X[i] = acc;
+    }
+    // m_t += J v  (thread = row)
+    {   // eight lanes per row, 12 columns each, summed with DPP-free shuffles inside the 8-lane group
+      const int row = tid >> 3, part = tid & 7;
+      double s = 0.0;
+      if (row < T)
+        for (int j = part; j < T; j += 8) s = fma(Jl[row * PITCH + j], vl[j], s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (row < T && part == 0) a.M[(size_t)t * T + row] += s;
+    }
+    __syncthreads();                       // every wave has finished reading D
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Dl[(16 * I + g + 4 * r) * PITCH + 16 * Jc + c] = X[i][r];
+    }
+    __syncthreads();
+    // C_t += X J^T
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int k = 0; k < 96; k += 4) acc = mfma(Dl[(16 * I + c) * PITCH + k + g], Jl[(16 * Jc + c) * PITCH + k + g], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r, col = 16 * Jc + c;
+        if (row < T && col < T) Ct[(size_t)row * T + col] += acc[r];
+      }
+    }
+    __threadfence();
+    __syncthreads();                       // C_t, m_t visible; LDS free for the next step
+  }
+}
+
 // k_chain_finish: matrix_normal_inv_wishart.posterior's element-wise tail for BOTH updates (GPI_model.py:1326-1336),
 // the keep-previous rule on a failed factorisation (GPI_model.py:1068-1071), the annealed scales
 // (GPI_model.py:1083-1091), the append of A, Gamma, C, Sigma and the counters - one workgroup, one launch.
@@ -808,10 +932,12 @@ struct ChainFinishArgs {
   double* stS;
   int64_t* pos;           // in/out: += 1
   int annealing;
+  int32_t* sync;          // one zero-initialised counter (left zero)
 };
 
 #pragma clang fp contract(off)   // the reference's op order, no fused multiply-adds
-__global__ __launch_bounds__(1024) void k_chain_finish(ChainFinishArgs a) {
+__global__ __launch_bounds__(256) void k_chain_finish(ChainFinishArgs a) {
+  __shared__ int last;
   const long tt = (long)a.T * a.T;
   const bool bad = (a.info1[0] | a.info1[1] | a.info2[0] | a.info2[1]) != 0;
   const double n0 = a.n0[0], Nf = a.Nf[0] + 1.0;
@@ -819,8 +945,7 @@ __global__ __launch_bounds__(1024) void k_chain_finish(ChainFinishArgs a) {
   const double n0n = bad ? n0 : n0 + 1.0;
   const double scl = n0n / (n0n - 2.0);
   const double ann = a.annealing ? 1.0 / (Nf * Nf) : 0.0;
-  __syncthreads();   // every thread has read the scalars before thread 0 rewrites them below
-  for (long i = threadIdx.x; i < 2 * tt; i += 1024) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 2 * tt; i += (long)gridDim.x * 256) {
     double m = a.W[i], r = a.W[2 * tt + i], sc = a.W[4 * tt + i];
     if (!bad) {
       m = ((n0 - 2.0) * m + a.part[i]) / (n0 - 1.0);
@@ -836,11 +961,19 @@ __global__ __launch_bounds__(1024) void k_chain_finish(ChainFinishArgs a) {
     double* sg = obs ? a.stS : a.stG;
     sg[nxt * tt + e] = sc * scl + sg[e] * ann;
   }
+  // the scalars are rewritten by whichever block finishes last: every block has read them by then
+  __syncthreads();
   if (threadIdx.x == 0) {
+    __threadfence();
+    last = (atomicAdd(a.sync, 1) == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
     a.n0[0] = n0n;
     a.Nf[0] = Nf;
     a.bad_count[0] += bad ? 1 : 0;
     a.pos[0] = nxt;
+    a.sync[0] = 0;
   }
 }
 #pragma clang fp contract(on)
@@ -2142,14 +2275,30 @@ int hgp_gemm_add_batched_f64(int transA, int transB, int M, int N, int Kd, doubl
   return launch_gemm(g, batch, (hipStream_t)stream);
 }
 
+int hgp_rts_chain_f64(const double* J, const double* P, const double* AM, double* M, double* Cv, int n, int T, void* stream) {
+  if (!J || !P || !AM || !M || !Cv || n < 0 || T <= 0) return -1;
+  if (T > 96) return -2;
+  if (n < 2) return 0;
+  RtsArgs a{J, P, AM, M, Cv, n, T};
+  const size_t lds = sizeof(double) * (2 * 96 * 100 + 96);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rts_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_rts_chain, dim3(1), dim3(64 * RTS_WAVES), lds, (hipStream_t)stream, a);
+  return launch_status();
+}
+
 int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const double* Snew, const int32_t* info1,
                              const int32_t* info2, double* W, double* n0, double* Nf, int32_t* bad_count, double* stA,
-                             double* stG, double* stC, double* stS, int64_t* pos, int annealing, void* stream) {
+                             double* stG, double* stC, double* stS, int64_t* pos, int annealing, int32_t* sync, void* stream) {
   if (!part || !ee || !Snew || !info1 || !info2 || !W || !n0 || !Nf || !bad_count || !stA || !stG || !stC || !stS || !pos ||
-      T <= 0)
+      !sync || T <= 0)
     return -1;
-  ChainFinishArgs a{T, part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing};
-  hipLaunchKernelGGL(k_chain_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  ChainFinishArgs a{T, part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing, sync};
+  const long n2 = 2L * T * T;
+  hipLaunchKernelGGL(k_chain_finish, dim3((unsigned)std::min<long>(64, (n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

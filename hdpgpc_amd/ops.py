@@ -280,6 +280,12 @@ def add_diag_mean(R, S, factor, out=None):
     return out
 
 
+def rts_chain(J, P, AM, M, Cv):
+    """Sequential part of the RTS smoother for all steps in one launch (in place on M [n,T] and Cv [n,T,T]); T <= 96."""
+    n, T = M.shape[0], Cv.shape[1]
+    _ffi.check(_ffi.lib.hgp_rts_chain_f64(_ptr(J), _ptr(P), _ptr(AM), _ptr(M), _ptr(Cv), n, T, _stream()), "rts_chain")
+
+
 def lds_chain_scatter(f_post, c_post, f_sm_prev, P_sm_prev, stF, stFsm, stP, stPsm, pos):
     """8f-1 glue: append the new filtered state (rows pos + 1) and overwrite the re-smoothed previous one (rows pos)."""
     T = stP.shape[1]
@@ -347,12 +353,12 @@ def lds_chain_gather(stA, stG, stC, stS, stP, stPsm, stF, stFsm, pos, out):
     return out
 
 
-def lds_chain_finish(part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing):
+def lds_chain_finish(part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing, sync):
     """8f-1 glue: element-wise tail of the two MNIW updates + append of A, Gamma, C, Sigma + counters (see the header)."""
     T = stA.shape[1]
     _ffi.check(_ffi.lib.hgp_lds_chain_finish_f64(T, _ptr(part), _ptr(ee), _ptr(Snew), _ptr(info1), _ptr(info2), _ptr(W), _ptr(n0),
                                                  _ptr(Nf), _ptr(bad_count), _ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(pos),
-                                                 int(bool(annealing)), _stream()), "lds_chain_finish")
+                                                 int(bool(annealing)), _ptr(sync), _stream()), "lds_chain_finish")
 
 
 def trsv_lower_quad(G, y):

@@ -166,10 +166,16 @@ int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const do
  *     n0' = n0 + 1 (unless bad);  Nf' = Nf + 1;  scl = n0' / (n0' - 2);  ann = annealing ? 1 / Nf'^2 : 0
  *     A[pos+1] = means'[0]; C[pos+1] = means'[1]; Gamma[pos+1] = scales'[0] scl + Gamma[0] ann; Sigma likewise
  *                                                        (bayesian_new_params, GPI_model.py:1076-1106)
- *     W = (means', R', scales') [3,2,T,T];  n0, Nf, bad_count, pos updated in place (pos += 1). */
+ *     W = (means', R', scales') [3,2,T,T];  n0, Nf, bad_count, pos updated in place (pos += 1).
+ *     sync: one int32 the caller zero-initialises once (inter-block counter, left at zero). */
 int hgp_lds_chain_gather_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stP,
                              const double* stPsm, const double* stF, const double* stFsm, const int64_t* pos, int T,
                              double* out, void* stream);
+/* hgp_rts_chain_f64: the sequential part of GPI.backward (GPI.py:240-270) for all n states in one launch, T <= 96
+ * (-2 above).  J[n-1,T,T] = c_t A_t^T P_t^{-1}, P[n-1,T,T] = A_t c_t A_t^T + Gamma_t and AM[n-1,T] = A_t m_t come from
+ * the FILTERED states (batched by the caller); in place, for t = n-2 .. 0:
+ *     M[t] += J[t] (M[t+1] - AM[t]);   Cv[t] += J[t] (Cv[t+1] - P[t]) J[t]^T. */
+int hgp_rts_chain_f64(const double* J, const double* P, const double* AM, double* M, double* Cv, int n, int T, void* stream);
 /* hgp_lds_chain_scatter_f64: f_star[pos+1] = f_star_sm[pos+1] = f_post; cov_f[pos+1] = cov_f_sm[pos+1] = c_post
  *   (include_sample, GPI_model.py:317); f_star_sm[pos] = f_sm_prev, cov_f_sm[pos] = P_sm_prev (backwards_pair,
  *   GPI_model.py:705-716). */
@@ -184,7 +190,7 @@ int hgp_gemm_add_batched_f64(int transA, int transB, int M, int N, int Kd, doubl
                              double* C, int ldc, long strideC, int batch, void* stream);
 int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const double* Snew, const int32_t* info1,
                              const int32_t* info2, double* W, double* n0, double* Nf, int32_t* bad_count, double* stA,
-                             double* stG, double* stC, double* stS, int64_t* pos, int annealing, void* stream);
+                             double* stG, double* stC, double* stS, int64_t* pos, int annealing, int32_t* sync, void* stream);
 
 /* a10 helper - || G^{-1} y ||^2 for the lower triangle G of a [T, ld] matrix.  IterativeGaussianProcess.
  * log_marginal_likelihood as written passes K itself as the "factor" to cho_solve (GPI.py:1043); this reproduces
