@@ -209,3 +209,43 @@ def test_replay_offline_trace_from_labels():
         q[:, mi] = qm.cpu().numpy()
     assert rel_err(q, g["q"]) < 1e-5
     assert np.array_equal(np.argmax(q, axis=1), np.argmax(g["q"], axis=1))
+
+
+def test_gemm_addend_epilogue_and_out():
+    rng = np.random.default_rng(21)
+    A, B, D = rng.normal(size=(3, 50, 70)), rng.normal(size=(3, 70, 33)), rng.normal(size=(50, 33))
+    out = torch.empty((3, 50, 33), dtype=torch.float64, device="cuda")
+    r = ops.gemm_batched(dev(A), dev(B), alpha=-0.5, add=dev(D), beta=2.0, out=out)
+    assert r is out
+    assert np.allclose(out.cpu().numpy(), -0.5 * A @ B + 2.0 * D, rtol=1e-12, atol=1e-12)
+    Dm = rng.normal(size=(3, 33, 33))
+    r2 = ops.gemm_batched(dev(B), dev(B), transA=True, add=dev(Dm))
+    assert np.allclose(r2.cpu().numpy(), B.transpose(0, 2, 1) @ B + Dm, rtol=1e-12, atol=1e-12)
+
+
+def test_add_diag_mean_is_the_mniw_jitter():
+    rng = np.random.default_rng(22)
+    R, S = rng.normal(size=(2, 37, 37)), rng.normal(size=(2, 37, 37))
+    got = ops.add_diag_mean(dev(R), dev(S), 1e-2).cpu().numpy()
+    for b in range(2):
+        jit = 1e-2 * max(np.mean(np.abs(np.diag(S[b]))), np.finfo(np.float64).eps)
+        assert np.allclose(got[b], R[b] + jit * np.eye(37), rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("T,n", [(90, 40), (33, 7), (96, 3)])
+def test_rts_chain_kernel_matches_the_sequential_recursion(T, n):
+    """hgp_rts_chain_f64: m_t += J_t (m_{t+1} - A_t m_t), C_t += J_t (C_{t+1} - P_t) J_t^T for t = n-2 .. 0, one launch."""
+    rng = np.random.default_rng(T + n)
+    J = rng.normal(size=(n - 1, T, T)) * 0.1
+    P = rng.normal(size=(n - 1, T, T))
+    AM = rng.normal(size=(n - 1, T))
+    M = rng.normal(size=(n, T))
+    Cv = rng.normal(size=(n, T, T))
+    Mg, Cg = dev(M), dev(Cv)
+    ops.rts_chain(dev(J), dev(P), dev(AM), Mg, Cg)
+    Mr, Cr = M.copy(), Cv.copy()
+    for t in range(n - 2, -1, -1):
+        Mr[t] = Mr[t] + J[t] @ (Mr[t + 1] - AM[t])
+        Cr[t] = Cr[t] + J[t] @ (Cr[t + 1] - P[t]) @ J[t].T
+    assert np.allclose(Mg.cpu().numpy(), Mr, rtol=1e-11, atol=1e-11)
+    assert np.allclose(Cg.cpu().numpy(), Cr, rtol=1e-11, atol=1e-11)
