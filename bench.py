@@ -111,7 +111,7 @@ def secondary_large_T(dev, ops, orc, N=1024, K=16, T=256, reps=3):
     assert int(info.abs().max()) == 0 and bool(torch.isfinite(quad).all())
     ms = e0.elapsed_time(e1) / reps
     tf = N * K * algorithmic_flops_per_eval(T) / (ms * 1e-3) / 1e12
-    return {"workload": f"configs[3] shape on one GPU: {N} segments x {K} clusters, T={T}, irregular grids (k_pairs_coop8)",
+    return {"workload": f"configs[3] shape on one GPU: {N} segments x {K} clusters, T={T}, irregular grids (k_pairs_cooph<16>)",
             "value": N * K / dt, "unit": "evals/s", "ms_per_step": dt * 1e3, "kernel_ms": ms,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T)}}

@@ -1852,13 +1852,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
 #endif
 }
 
-// The same pipeline with EIGHT waves per pair (two per SIMD) for 192 < T <= 256: 17 tiles per wave (Coop8, tile_f64.hpp)
-// instead of 34-40, so the latencies and barrier waits of one wave sit under the MFMAs of the other on the same SIMD.
-__global__ __launch_bounds__(64 * Coop8::NW) void k_pairs_coop8(PairsArgs a) {
-  using PC = PairsCoop<16>;
-  constexpr int NB = 16, NW = Coop8::NW;
+// The same pipeline with NB/2 waves per pair (CoopH<NB>, tile_f64.hpp: 8 waves and 17 tiles per wave at NB = 16 instead
+// of 4 waves and 34-40 tiles): more than one wave per SIMD, so the latencies and barrier waits of one wave sit under the
+// MFMAs of another.
+template <int NB>
+__global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs_cooph(PairsArgs a) {
+  using PC = PairsCoop<NB>;
+  using H = CoopH<NB>;
+  constexpr int NW = H::NW;
   constexpr int TP = 16 * NB, CAP = PC::CAP;
-  constexpr int CH = 2;   // row tiles of B[:, J] per pass
+  constexpr int CH = (NB <= 8 && NB % 4 == 0) ? 4 : 2;   // row tiles of B[:, J] per pass (must divide NB; register budget)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ec = smem;                    // [CAP][4][64]
   double* rowbuf = Ec + CAP * 256;      // [NB][4][64]
@@ -2044,7 +2047,9 @@ __global__ __launch_bounds__(64 * Coop8::NW) void k_pairs_coop8(PairsArgs a) {
     if (tid == 0) {
       const double v = sc[4] + fn;
       const double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
-      a.out_quad[oidx] = (red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7]) / v2;
+      double tot_ = 0.0;
+      for (int w_ = 0; w_ < NW; ++w_) tot_ += red[w_];
+      a.out_quad[oidx] = tot_ / v2;
       if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
       if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
     }
@@ -2059,15 +2064,15 @@ __global__ __launch_bounds__(64 * Coop8::NW) void k_pairs_coop8(PairsArgs a) {
     bas[I] = __builtin_amdgcn_readfirstlane(base[I]);
   }
   const double* Mk = a.Mp + (size_t)kc * TP * TP;   // plain row-major here (no tile-pair interleave)
-  d4 U[Coop8::NT];
+  d4 U[H::NT];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int J = (q == 0) ? wave : 15 - wave;   // my block columns: A (rows 0..wave) and B (rows 0..15-wave)
+    const int J = (q == 0) ? wave : NB - 1 - wave;   // my block columns: A (rows 0..wave) and B (rows 0..NB-1-wave)
     const int mJ = __builtin_amdgcn_readfirstlane(amask[J]), bJ = __builtin_amdgcn_readfirstlane(base[J]);
     const int kmJ = __builtin_amdgcn_readfirstlane(kmask[J]), need = __builtin_amdgcn_readfirstlane(pneed[J]);
     // K** = c exp(-0.5 (x_i - x_j)^2) + noise I on my column (the one-argument kernel call, GPI.py:476)
 #pragma unroll
-    for (int I = 0; I < (q == 0 ? 8 : 16); ++I) {
+    for (int I = 0; I < (q == 0 ? NW : NB); ++I) {
       const int ln = launder(lane);
       d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
       if (I <= J) {
@@ -2084,7 +2089,7 @@ __global__ __launch_bounds__(64 * Coop8::NW) void k_pairs_coop8(PairsArgs a) {
             if ((ln >> 4) + 4 * r == (ln & 15)) kt[r] = (16 * I + (ln & 15) < Ts) ? cc + noise : 1.0;
         }
       }
-      if (I <= J) U[q == 0 ? Coop8::slotA(I) : Coop8::slotB(I)] = kt;   // (slots of rows I > J belong to the other column)
+      if (I <= J) U[q == 0 ? H::slotA(I) : H::slotB(I)] = kt;   // (slots of rows I > J belong to the other column)
     }
     HGP_ACC(2);
 #pragma nounroll
@@ -2141,7 +2146,7 @@ __global__ __launch_bounds__(64 * Coop8::NW) void k_pairs_coop8(PairsArgs a) {
       // sweep 2: U[I][J] += E[Kt, I]^T BJ[i] over the active blocks (Kt = 4h + i, I <= J) of E.  Per tile the operands
       // of all its active blocks in this chunk are requested first, then multiplied: one LDS latency per tile.
 #pragma unroll
-      for (int I = 0; I < (q == 0 ? 8 : 16); ++I) {
+      for (int I = 0; I < (q == 0 ? NW : NB); ++I) {
         const int m4 = (msk[I] >> (CH * h)) & nb4;
         if (I <= J && m4) {
           const int below = __popc(msk[I] & ((1 << (CH * h)) - 1));
@@ -2158,7 +2163,7 @@ __global__ __launch_bounds__(64 * Coop8::NW) void k_pairs_coop8(PairsArgs a) {
           for (int i = 0; i < CH; ++i) {
             if (m4 & (1 << i)) {
 #pragma unroll
-              for (int s = 0; s < 4; ++s) U[q == 0 ? Coop8::slotA(I) : Coop8::slotB(I)] = mfma(af[i][s], BJ[i][s], U[q == 0 ? Coop8::slotA(I) : Coop8::slotB(I)]);
+              for (int s = 0; s < 4; ++s) U[q == 0 ? H::slotA(I) : H::slotB(I)] = mfma(af[i][s], BJ[i][s], U[q == 0 ? H::slotA(I) : H::slotB(I)]);
             }
           }
         }
@@ -2172,20 +2177,22 @@ __global__ __launch_bounds__(64 * Coop8::NW) void k_pairs_coop8(PairsArgs a) {
   // regularisation of the reference: +1e-6 I (GPI.py:501), + first, + 1e-8 mean|diag| I (GPI_model.py:83-87)
   {
     const double sh = 1e-6 + fn;
-    const double dm = coop8_diag_abs_mean(U, Ts, wave, lane, sh, red);   // (also orders the dvec writes: barrier)
-    coop8_add_diag(U, sh + 1e-8 * fmax(dm, F64_EPS), Ts, wave, lane);
+    const double dm = cooph_diag_abs_mean<NB>(U, Ts, wave, lane, sh, red);   // (also orders the dvec writes: barrier)
+    cooph_add_diag<NB>(U, sh + 1e-8 * fmax(dm, F64_EPS), Ts, wave, lane);
   }
   PivotAcc pa;
   pa.init();
   HGP_ACC(5);
-  double zq = coop8_factor(U, rowbuf, Wbuf, scr, wave, lane, pa, Ts, dvec);
+  double zq = cooph_factor<NB>(U, rowbuf, Wbuf, scr, wave, lane, pa, Ts, dvec);
   int info;
-  const double ld = coop8_logdet_info(pa, wave, lane, red, redi, info);
+  const double ld = cooph_logdet_info<NB>(pa, wave, lane, red, redi, info);
   zq = wave_sum(zq);
   if (lane == 0) red[8 + wave] = zq;
   __syncthreads();
   if (tid == 0) {
-    a.out_quad[oidx] = red[8] + red[9] + red[10] + red[11] + red[12] + red[13] + red[14] + red[15];
+    double tot_ = 0.0;
+    for (int w_ = 0; w_ < NW; ++w_) tot_ += red[8 + w_];
+    a.out_quad[oidx] = tot_;
     if (a.out_logdet) a.out_logdet[oidx] = ld;
     if (a.out_info) a.out_info[oidx] = info;
   }
@@ -2198,15 +2205,16 @@ __global__ __launch_bounds__(64 * Coop8::NW) void k_pairs_coop8(PairsArgs a) {
 #endif
 }
 
-int launch_pairs_coop8(const PairsArgs& a, hipStream_t st) {
-  const size_t lds = PairsCoop<16>::LDS_BYTES;
+template <int NB>
+int launch_pairs_cooph(const PairsArgs& a, hipStream_t st) {
+  const size_t lds = PairsCoop<NB>::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs_coop8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs_cooph<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int blocks = a.sel ? a.N : a.N * (a.kend - a.kbeg);
-  hipLaunchKernelGGL(k_pairs_coop8, dim3(blocks), dim3(64 * Coop8::NW), lds, st, a);
+  hipLaunchKernelGGL(k_pairs_cooph<NB>, dim3(blocks), dim3(64 * CoopH<NB>::NW), lds, st, a);
   return launch_status();
 }
 
@@ -2261,7 +2269,8 @@ static int tp_for(int n) {   // padded size: wave kernels {32,64,96,128}, cooper
   if (n <= HGP_MAX_T_WAVE) return 16 * nb_for(n);
   return n <= 192 ? 192 : 256;
 }
-// Diagnostic switch (read when a plan is created): HGP_PAIRS_COOP=1 runs the cooperative kernel for T <= 128 too.
+// Diagnostic switches: HGP_PAIRS_COOP=1 (read when a plan is created) runs the cooperative kernels for T <= 128 too;
+// HGP_PAIRS_COOP4=1 (read per call) selects the 4-wave cooperative kernel instead of the NB/2-wave one.
 static bool env_on(const char* name) {
   const char* v = getenv(name);
   return v && v[0] && v[0] != '0';
@@ -2485,12 +2494,13 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
                 g_stamp_dev,
 #endif
                 p->K, out_quad, out_logdet, out_info, p->d_escr, p->d_eflags, p->nscr, p->escr_stride};
-    if (p->coop) {
+    if (p->coop) {   // NB/2 waves per pair (CoopH); HGP_PAIRS_COOP4=1 selects the 4-wave kernels (Coop) for comparison
+      const bool four = env_on("HGP_PAIRS_COOP4");
       switch (p->NB) {
         case 4: rc = launch_pairs_coop<4>(a, st); break;
-        case 8: rc = launch_pairs_coop<8>(a, st); break;
-        case 12: rc = launch_pairs_coop<12>(a, st); break;
-        default: rc = env_on("HGP_PAIRS_COOP4") ? launch_pairs_coop<16>(a, st) : launch_pairs_coop8(a, st); break;
+        case 8: rc = four ? launch_pairs_coop<8>(a, st) : launch_pairs_cooph<8>(a, st); break;
+        case 12: rc = four ? launch_pairs_coop<12>(a, st) : launch_pairs_cooph<12>(a, st); break;
+        default: rc = four ? launch_pairs_coop<16>(a, st) : launch_pairs_cooph<16>(a, st); break;
       }
       continue;
     }

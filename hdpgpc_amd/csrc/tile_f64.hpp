@@ -747,34 +747,38 @@ __device__ __forceinline__ double coop_logdet_info(const PivotAcc& pa, int wave,
 }
 
 // =============================================================================================
-// 8-wave cooperative version for NB = 16 (192 < T <= 256): two waves per SIMD, so that the LDS/scalar latencies and the
-// barrier waits of one wave sit under the MFMAs of the other.  Wave w owns block columns w ("A": tiles (I, w), I <= w)
-// and 15 - w ("B": tiles (I, 15 - w), I <= 15 - w): EXACTLY 17 tiles per wave, with slots that do not depend on w -
-//     slotA(I) = 16 - I,   slotB(I) = I       (A uses 16-w..16, B uses 0..15-w: disjoint for every w)
+// NB/2-wave cooperative version (CoopH<NB>: 8 waves at NB = 16, 6 at NB = 12, 4 at NB = 8): more than one wave per SIMD,
+// so that the LDS/scalar latencies and the barrier waits of one wave sit under the MFMAs of another.  Wave w owns block
+// columns w ("A": tiles (I, w), I <= w) and NB-1-w ("B": tiles (I, NB-1-w), I <= NB-1-w): EXACTLY NB + 1 tiles per wave,
+// with slots that do not depend on w -
+//     slotA(I) = NB - I,   slotB(I) = I       (A uses NB-w..NB, B uses 0..NB-1-w: disjoint for every w)
 // so the register array is indexed statically.  Same step structure as coop_factor (diagonal block by the column owner,
 // row panel and trailing update by column owner, two barriers per step); the right-hand side is ONE vector in LDS.
 // =============================================================================================
-struct Coop8 {
-  static constexpr int NB = 16, NT = 17, NW = 8;
-  __host__ __device__ static constexpr int slotA(int I) { return 16 - I; }
+template <int NB_>
+struct CoopH {
+  static_assert(NB_ % 2 == 0 && NB_ <= 16, "CoopH: even NB <= 16");
+  static constexpr int NB = NB_, NT = NB_ + 1, NW = NB_ / 2;
+  __host__ __device__ static constexpr int slotA(int I) { return NB - I; }
   __host__ __device__ static constexpr int slotB(int I) { return I; }
-  __host__ __device__ static constexpr int owner(int J) { return J < 8 ? J : 15 - J; }
-  __host__ __device__ static constexpr int diag_slot(int K) { return K < 8 ? slotA(K) : slotB(K); }
+  __host__ __device__ static constexpr int owner(int J) { return J < NW ? J : NB - 1 - J; }
+  __host__ __device__ static constexpr int diag_slot(int K) { return K < NW ? slotA(K) : slotB(K); }
 };
 
 // mean over i < n of |A_ii + shift| (LDS reduction in red[8])
-__device__ __forceinline__ double coop8_diag_abs_mean(const d4 (&U)[Coop8::NT], int n, int wave, int lane_in, double shift,
+template <int NB>
+__device__ __forceinline__ double cooph_diag_abs_mean(const d4 (&U)[CoopH<NB>::NT], int n, int wave, int lane_in, double shift,
                                                       double* red) {
   double s = 0.0;
 #pragma unroll
-  for (int K = 0; K < 16; ++K) {
+  for (int K = 0; K < NB; ++K) {
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;
-    if (wave == Coop8::owner(K)) {
+    if (wave == CoopH<NB>::owner(K)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * K + g + 4 * r;
-        if (g + 4 * r == c && i < n) s += fabs(U[Coop8::diag_slot(K)][r] + shift);
+        if (g + 4 * r == c && i < n) s += fabs(U[CoopH<NB>::diag_slot(K)][r] + shift);
       }
     }
   }
@@ -783,34 +787,36 @@ __device__ __forceinline__ double coop8_diag_abs_mean(const d4 (&U)[Coop8::NT], 
   __syncthreads();
   double tot = 0.0;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) tot += red[w];
+  for (int w = 0; w < CoopH<NB>::NW; ++w) tot += red[w];
   __syncthreads();
   return tot / (double)n;
 }
 
-__device__ __forceinline__ void coop8_add_diag(d4 (&U)[Coop8::NT], double shift, int n, int wave, int lane_in) {
+template <int NB>
+__device__ __forceinline__ void cooph_add_diag(d4 (&U)[CoopH<NB>::NT], double shift, int n, int wave, int lane_in) {
 #pragma unroll
-  for (int K = 0; K < 16; ++K) {
+  for (int K = 0; K < NB; ++K) {
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;
-    if (wave == Coop8::owner(K)) {
+    if (wave == CoopH<NB>::owner(K)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * K + g + 4 * r;
-        if (g + 4 * r == c && i < n) U[Coop8::diag_slot(K)][r] += shift;
+        if (g + 4 * r == c && i < n) U[CoopH<NB>::diag_slot(K)][r] += shift;
       }
     }
   }
 }
 
 // Factor + eliminate the single right-hand side dvec (on exit z = L^{-1} d); returns this wave's share of z^T z.
-__device__ __forceinline__ double coop8_factor(d4 (&U)[Coop8::NT], double* rowbuf, double* Wbuf, double* scr, int wave,
+template <int NB>
+__device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* rowbuf, double* Wbuf, double* scr, int wave,
                                                int lane_in, PivotAcc& pa, int n, double* dvec) {
-  using C = Coop8;
+  using C = CoopH<NB>;
   double zq = 0.0;
-  const int JA = wave, JB = 15 - wave;   // my block columns
+  const int JA = wave, JB = NB - 1 - wave;   // my block columns
 #pragma unroll
-  for (int K = 0; K < 16; ++K) {
+  for (int K = 0; K < NB; ++K) {
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;
     if (wave == C::owner(K)) {
@@ -837,7 +843,7 @@ __device__ __forceinline__ double coop8_factor(d4 (&U)[Coop8::NT], double* rowbu
     // panel + right-hand side for my columns J > K: slot of tile (K, J) is slotA(K) for J = JA, slotB(K) for J = JB
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (h == 0 && K >= 8) continue;             // column A has rows 0..w <= 7 only
+      if (h == 0 && K >= C::NW) continue;         // column A has rows 0..w <= NW - 1 only
       const int J = h == 0 ? JA : JB;
       const int sl = h == 0 ? C::slotA(K) : C::slotB(K);
       if (J > K) {
@@ -856,13 +862,13 @@ __device__ __forceinline__ double coop8_factor(d4 (&U)[Coop8::NT], double* rowbu
     }
     __syncthreads();
     // trailing: A_IJ -= U_KI^T U_KJ for my columns J >= I > K
-    if (K + 1 < 16) {
+    if (K + 1 < NB) {
       d4 ucur = lds_tile_load(rowbuf, K + 1, lane);
 #pragma unroll
-      for (int I = K + 1; I < 16; ++I) {
+      for (int I = K + 1; I < NB; ++I) {
         d4 unext = ucur;
-        if (I + 1 < 16) unext = lds_tile_load(rowbuf, I + 1, lane);
-        if (I < 8 && K < 8 && JA >= I) {          // tile (I, JA): needs I <= w <= 7
+        if (I + 1 < NB) unext = lds_tile_load(rowbuf, I + 1, lane);
+        if (I < C::NW && K < C::NW && JA >= I) {   // tile (I, JA): needs I <= w <= NW - 1
 #pragma unroll
           for (int s = 0; s < 4; ++s) U[C::slotA(I)] = mfma_sub(ucur[s], U[C::slotA(K)][s], U[C::slotA(I)]);
         }
@@ -878,7 +884,8 @@ __device__ __forceinline__ double coop8_factor(d4 (&U)[Coop8::NT], double* rowbu
   return zq;
 }
 
-__device__ __forceinline__ double coop8_logdet_info(const PivotAcc& pa, int wave, int lane, double* red, int* redi, int& info) {
+template <int NB>
+__device__ __forceinline__ double cooph_logdet_info(const PivotAcc& pa, int wave, int lane, double* red, int* redi, int& info) {
   if (lane == 0) {
     red[wave] = pa.logdet();
     redi[wave] = pa.info;
@@ -887,7 +894,7 @@ __device__ __forceinline__ double coop8_logdet_info(const PivotAcc& pa, int wave
   double ld = 0.0;
   int inf = 0;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) {
+  for (int w = 0; w < CoopH<NB>::NW; ++w) {
     ld += red[w];
     if (redi[w] != 0 && (inf == 0 || redi[w] < inf)) inf = redi[w];
   }
