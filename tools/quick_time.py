@@ -60,3 +60,15 @@ for (b, T) in [(16, 256), (1024, 256), (4096, 128), (4096, 90)]:
     f = lambda: _ffi.check(_ffi.lib.hgp_chol_rank1_f64(ops._ptr(Lw), ops._ptr(v), ops._ptr(al), ops._ptr(be), T, b, ops._ptr(info), ops._stream()), "r1")
     t = timeit(f, n=3, w=1)
     print(f"chol_rank1 b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} updates/s, {b*T*T*8/t/1e9:.1f} GB/s (algorithmic: lower triangle in and out)", flush=True)
+
+# a8 / a9: matrix-valued likelihood terms, batched
+for (b, T) in [(2272, 90), (256, 90), (16, 90), (1024, 128)]:
+    rng = np.random.default_rng(1)
+    Q = rng.normal(size=(8, T, T)); G = Q @ Q.transpose(0, 2, 1) / T + np.eye(T)
+    Gam = dev(np.tile(G, (b // 8 + 1, 1, 1))[:b]); A = dev(rng.normal(size=(b, T, T)) * 0.1); cp = dev(np.tile(G, (b // 8 + 1, 1, 1))[:b])
+    fc, fp = dev(rng.normal(size=(b, T))), dev(rng.normal(size=(b, T)))
+    t = timeit(lambda: ops.lat_error(fc, fp, A, Gam, cp), n=3, w=1)
+    print(f"lat_error (a8)   b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} evals/s", flush=True)
+    M = dev(rng.normal(size=(b, T, T))); m0 = dev(np.eye(T)); sc = dev(G[0])
+    t = timeit(lambda: ops.mniw_loglik(M, Gam, m0, None, sc), n=3, w=1)
+    print(f"mniw_loglik (a9) b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} evals/s", flush=True)
