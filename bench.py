@@ -87,11 +87,11 @@ def secondary_shared_grid(dev, ops, S=16384, T=90, reps=10):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
 
 
-def secondary_large_T(dev, ops, orc, N=1024, K=16, T=256, reps=3):
+def secondary_large_T(dev, ops, synth, N=1024, K=16, T=256, reps=3):
     """BASELINE configs[3] shape on ONE GPU (a quarter of its 4 096 segments per GPU): 16 clusters, T = 256, irregular
     grids - the cooperative pairs kernel (one workgroup per pair).  Same accounting as the headline: algorithmic
     FLOPs T^3/3 + 3T^2 per eval against the fp64 MFMA peak."""
-    b = orc.synthetic_batch(N, K, T, seed=20260703)
+    b = synth.synthetic_batch(N, K, T, seed=20260703)
     d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
     plan = ops.PairsPlan(T, T, b["theta"], device=dev)
     xb, mean, Sig, x, y = d(b["xb"]), d(b["mean"]), d(b["Sigma"]), d(b["x"]), d(b["y"])
@@ -177,11 +177,11 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    import synthetic_workload as synth        # workload generator: plain NumPy, independent of oracle/
     from hdpgpc_amd import ops
-    from oracle import hdpgpc_oracle as orc   # synthetic workload generator only; never in the timed path
 
-    batch = orc.synthetic_batch(N_SEG, K_CL, T_LEN, seed=20260703 + rank)
-    cl = orc.synthetic_batch(1, K_CL, T_LEN, seed=20260703)          # cluster state is replicated: same on every rank
+    batch = synth.synthetic_batch(N_SEG, K_CL, T_LEN, seed=20260703 + rank)
+    cl = synth.synthetic_batch(1, K_CL, T_LEN, seed=20260703)          # cluster state is replicated: same on every rank
     for k in ("xb", "theta", "mean", "Sigma"):
         batch[k] = cl[k]
     d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
@@ -251,7 +251,7 @@ def main():
         }
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_shared_grid(dev, ops)
-            res["secondary_large_T"] = secondary_large_T(dev, ops, orc)
+            res["secondary_large_T"] = secondary_large_T(dev, ops, synth)
             res["secondary_rank1"] = secondary_rank1(dev, ops)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
