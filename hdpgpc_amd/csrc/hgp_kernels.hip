@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_potrf(PotrfArgs a) {
   const int T = a.T;
   d4 U[NB * (NB + 1) / 2];
   d4 R[NB];
-  load_sym_upper<NB>(U, A, T, T, lane);
+  load_sym_upper<NB>(U, A, T, T, lane, scr);
   if (a.add != 0.0) add_diag<NB>(U, a.add, T, lane);
   if (a.jitter_rel != 0.0) {
     double dm = diag_abs_mean<NB>(U, T, lane);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_inv(PotrfArgs a) {
   const double* A = a.A + (size_t)m * T * T;
   d4 U[NB * (NB + 1) / 2];
   d4 R[NB];
-  load_sym_upper<NB>(U, A, T, T, lane);
+  load_sym_upper<NB>(U, A, T, T, lane, scr);
   {
     double sh = a.add;
     if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(diag_abs_mean<NB>(U, T, lane, a.add), F64_EPS);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_score(ScoreArgs a) {
   d4 U[NB * (NB + 1) / 2];
   d4 R[NB];
   double* Wl = w_all + wave * NB * 256;
-  load_sym_upper<NB>(U, S, a.ld_sigma, T, lane);
+  load_sym_upper<NB>(U, S, a.ld_sigma, T, lane, scr);
   const double add = a.item_add ? a.item_add[it] : 0.0;
   if (add != 0.0) add_diag<NB>(U, add, T, lane);
   if (a.jitter_rel != 0.0) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 6) ? 2 : 1) void k_wave_score1(E
   d4 U[NB * (NB + 1) / 2];
   d4 Rnone[NB];
   if (a.symmetric) load_upper_only<NB>(U, S, T, T, lane);
-  else load_sym_upper<NB>(U, S, T, T, lane);
+  else load_sym_upper<NB>(U, S, T, T, lane, scr);
   {
     double sh = a.seg_add ? a.seg_add[seg] : 0.0;
     if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(diag_abs_mean<NB>(U, T, lane, sh), F64_EPS);

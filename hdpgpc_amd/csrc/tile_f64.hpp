@@ -409,25 +409,45 @@ __device__ __forceinline__ double wave_colnorm2(const d4 (&Z)[NB]) {
 // Loaders.  A is row-major with leading dimension ld, logical size n x n (n <= 16 NB); rows/cols
 // >= n are padded with the identity so the padded factorisation leaves quad/logdet unchanged.
 // ---------------------------------------------------------------------------------------------
-// symmetrised upper tiles:  0.5 (A + A^T)
+// symmetrised upper tiles:  0.5 (A + A^T).  Every global access is coalesced: tile (I, J) AND tile (J, I) are read in
+// their natural row-major order (16 lanes = 128 contiguous bytes) and the second is transposed through the wave's
+// 16 x 18 LDS staging tile.  (The first version read A[j][i] directly: 16 cache lines per load instruction; PMC showed
+// 56-65 % of the wave cycles of k_wave_inv / k_wave_score1 in s_waitcnt.)  One block row at a time: its 2 (NB - I) - 1
+// tile loads are all in flight before the first transpose.
 template <int NB>
 __device__ __forceinline__ void load_sym_upper(d4 (&U)[NB * (NB + 1) / 2], const double* __restrict__ A, int ld, int n,
-                                               int lane_in) {
+                                               int lane_in, double* scr) {
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+    d4 nat[NB], trn[NB];
 #pragma unroll
     for (int J = I; J < NB; ++J) {
-      const int lane = launder(lane_in);
-      const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;          // natural element of tile (I, J)
+        nat[J][r] = (i < n && j < n) ? A[(size_t)i * ld + j] : 0.0;
+        const int i2 = 16 * J + g + 4 * r, j2 = 16 * I + c;        // natural element of tile (J, I)
+        trn[J][r] = (J > I && i2 < n && j2 < n) ? A[(size_t)i2 * ld + j2] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int J = I; J < NB; ++J) {
+      const d4 src = (J == I) ? nat[I] : trn[J];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scr[(g + 4 * r) * DIAG_LD + c] = src[r];
+      __builtin_amdgcn_wave_barrier();
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int i = 16 * I + g + 4 * r, j = 16 * J + c;
-        double x = 0.0;
-        if (i < n && j < n) x = 0.5 * (A[(size_t)i * ld + j] + A[(size_t)j * ld + i]);
-        else if (i == j) x = 1.0;
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;
+        const double t = scr[c * DIAG_LD + g + 4 * r];               // element (c, g + 4r) of src = A[j][i]
+        double x = 0.5 * (nat[J][r] + t);
+        if (!(i < n && j < n)) x = (i == j) ? 1.0 : 0.0;
         v[r] = x;
       }
+      __builtin_amdgcn_wave_barrier();
       U[tix(I, J, NB)] = v;
     }
   }
