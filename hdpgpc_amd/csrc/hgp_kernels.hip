@@ -308,7 +308,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_score(ScoreArgs a) {
   const int off = a.item_off[it], cnt = a.item_cnt[it];
   d4 U[C::NT];
   for (int base = 0; base < cnt; base += 16) {     // every chunk of 16 segments refactors (rare for T > 128)
-    coop_load_sym_upper<NB>(U, S, a.ld_sigma, T, wave, lane);
+    coop_load_sym_upper<NB>(U, S, a.ld_sigma, T, wave, lane, rowbuf + wave * DIAG_SCR);
+    __syncthreads();   // rowbuf served as per-wave staging for the loader
     {
       double sh = add;
       if (a.jitter_rel != 0.0) {
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_potrf(PotrfArgs a) {
   const int T = a.T;
   double* A = a.A + (size_t)m * T * T;
   d4 U[C::NT];
-  coop_load_sym_upper<NB>(U, A, T, T, wave, lane);
+  coop_load_sym_upper<NB>(U, A, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
+  __syncthreads();   // rowbuf served as per-wave staging for the loader
   {
     double sh = a.add;
     if (a.jitter_rel != 0.0) {
@@ -414,7 +416,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_inv(PotrfArgs a) {
   if (16 * Jc >= T) return;
   const double* A = a.A + (size_t)m * T * T;
   d4 U[C::NT];
-  coop_load_sym_upper<NB>(U, A, T, T, wave, lane);
+  coop_load_sym_upper<NB>(U, A, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
+  __syncthreads();   // rowbuf served as per-wave staging for the loader
   {
     double sh = a.add;
     if (a.jitter_rel != 0.0) {

@@ -546,25 +546,41 @@ __device__ __forceinline__ void lds_tile_store(double* buf, int tile, int lane, 
 
 template <int NB>
 __device__ __forceinline__ void coop_load_sym_upper(d4 (&U)[Coop<NB>::NT], const double* __restrict__ A, int ld, int n,
-                                                    int wave, int lane_in) {
+                                                    int wave, int lane_in, double* scr_w) {
+  // scr_w: a 16 x 18 LDS staging tile private to this wave.  As in load_sym_upper both triangles are read coalesced
+  // and the lower one is transposed through LDS; a block column (the tiles this wave owns) at a time.
 #pragma unroll
   for (int q = 0; q < Coop<NB>::NQ; ++q) {
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+    const int J = Coop<NB>::col(q, wave);
+    d4 nat[NB], trn[NB];
 #pragma unroll
     for (int I = 0; I < 4 * q + 4; ++I) {
-      const int lane = launder(lane_in);
-      const int g = lane >> 4, c = lane & 15;
-      const int J = Coop<NB>::col(q, wave);
-      d4 v = (d4){0.0, 0.0, 0.0, 0.0};
-      if (I <= J && J < NB) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * I + g + 4 * r, j = 16 * J + c;
-          double x = 0.0;
-          if (i < n && j < n) x = 0.5 * (A[(size_t)i * ld + j] + A[(size_t)j * ld + i]);
-          else if (i == j) x = 1.0;
-          v[r] = x;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;          // natural element of tile (I, J)
+        nat[I][r] = (I <= J && i < n && j < n) ? A[(size_t)i * ld + j] : 0.0;
+        const int i2 = 16 * J + g + 4 * r, j2 = 16 * I + c;        // natural element of tile (J, I)
+        trn[I][r] = (I < J && i2 < n && j2 < n) ? A[(size_t)i2 * ld + j2] : 0.0;
       }
+    }
+#pragma unroll
+    for (int I = 0; I < 4 * q + 4; ++I) {
+      const d4 src = (I == J) ? nat[I] : trn[I];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scr_w[(g + 4 * r) * DIAG_LD + c] = src[r];
+      __builtin_amdgcn_wave_barrier();
+      d4 v = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;
+        const double t = scr_w[c * DIAG_LD + g + 4 * r];
+        double x = 0.5 * (nat[I][r] + t);
+        if (!(i < n && j < n)) x = (i == j) ? 1.0 : 0.0;
+        if (I <= J) v[r] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
       U[Coop<NB>::loc(I, q)] = v;
     }
   }
