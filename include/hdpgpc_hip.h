@@ -26,10 +26,10 @@
 extern "C" {
 #endif
 
-#define HGP_ABI_VERSION 1
+#define HGP_ABI_VERSION 2   /* 2: + hgp_gemm_add_batched_f64, hgp_add_diag_mean_f64, hgp_lds_chain_*_f64, hgp_rts_chain_f64 */
 /* largest T (basis length) and T* (segment length) served by the register-resident wave kernels */
 #define HGP_MAX_T_WAVE 128
-/* largest T served at all: 128 < T <= 256 runs on 4-wave cooperative kernels (one workgroup per matrix) */
+/* largest T served at all: 128 < T <= 256 runs on cooperative kernels (one workgroup of 4-8 waves per matrix / pair) */
 #define HGP_MAX_T_COOP 256
 
 int hgp_abi_version(void);
