@@ -128,11 +128,12 @@ class IterativeGaussianProcess:
 
     def log_marginal_likelihood(self, x_train, y_train, alpha_ini=None, theta=None, eval_gradient=False,
                                 clone_kernel=True, faithful=True):
-        """GPI.py:976-1056, value only.  ``faithful=True`` reproduces the reference as written (it hands K, not L,
-        to cho_solve, GPI.py:1043); ``faithful=False`` is the textbook value."""
-        if eval_gradient:
-            raise NotImplementedError("gradient of the LML belongs to the kernel fit (SURVEY.md 8f-2)")
+        """GPI.py:976-1056 (value, and with eval_gradient the gradient w.r.t. the log-parameters, GPI.py:1046-1051).
+        ``faithful=True`` reproduces the reference as written (it hands K, not L, to cho_solve, GPI.py:1043);
+        ``faithful=False`` is the textbook value."""
         kernel = self.kernel if theta is None else self.kernel.clone_with_theta(theta)
+        if eval_gradient and theta is None:
+            raise ValueError("Gradient can only be evaluated for theta!=None")     # GPI.py:1017-1020
         x = self.cond_to_torch(x_train).reshape(-1)
         y = self.cond_to_torch(y_train).reshape(1, -1).contiguous()
         K = kernel(x)
@@ -140,9 +141,23 @@ class IterativeGaussianProcess:
         items = ops.build_items([0], [0.0], [1])
         quad, logdet, info = ops.score_groups(y, None, K, *items, jitter_rel=0.0, want_logdet=True)
         if int(info[0]) != 0:
-            return -np.inf                                        # GPI.py:1035-1037
+            return (-np.inf, np.zeros(3)) if eval_gradient else -np.inf      # GPI.py:1035-1037
+        alpha = None
         if faithful:
-            quad0 = ops.trsv_lower_quad(K, y)
+            alpha, quad0 = ops.trsv_lower_solve(K, y) if eval_gradient else (None, ops.trsv_lower_quad(K, y))
         else:
             quad0 = quad[0]
-        return float(-0.5 * quad0 - 0.5 * logdet[0] - T / 2.0 * math.log(2.0 * math.pi))
+        val = float(-0.5 * quad0 - 0.5 * logdet[0] - T / 2.0 * math.log(2.0 * math.pi))
+        if not eval_gradient:
+            return val
+        # gradient w.r.t. the log-parameters (GPI.py:1046-1051): K^{-1} = Z^T Z with Z = chol(K)^{-1}
+        if T <= 128:
+            Z, _ = ops.chol_inverse(K)
+        else:
+            _, _, Z = ops.potrf_batched(K, 0.0, 0.0, want_inv=True)
+        Kinv = ops.gemm_batched(Z[0], Z[0], transA=True)
+        if alpha is None:
+            alpha = ops.gemm_batched(Kinv, y.reshape(-1, 1)).reshape(-1)
+        c, ell, noise = kernel.params()
+        grad = ops.lml_grad(x, alpha, Kinv, c, ell, noise)
+        return val, grad.cpu().numpy()

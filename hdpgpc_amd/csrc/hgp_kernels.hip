@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256) void k_chain_finish(ChainFinishArgs a) {
 // a10 (reference as written, GPI.py:1043): || G^{-1} y ||^2 with G = tril(K) used as if it were a Cholesky factor.
 // One workgroup, column-oriented forward substitution in LDS; T <= 2048.
 __global__ __launch_bounds__(256) void k_trsv_lower_quad(const double* __restrict__ G, int ld, const double* __restrict__ y,
-                                                          int T, double* __restrict__ out) {
+                                                          int T, double* __restrict__ out, double* __restrict__ alpha) {
   extern __shared__ double w[];
   for (int i = threadIdx.x; i < T; i += 256) w[i] = y[i];
   __syncthreads();
@@ -1004,7 +1004,51 @@ __global__ __launch_bounds__(256) void k_trsv_lower_quad(const double* __restric
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = red[0];
+  if (threadIdx.x == 0 && out) out[0] = red[0];
+  if (alpha) {   // alpha = G^{-T} w  (cho_solve((G, True), y), the second half of the reference's call)
+    for (int k = T - 1; k >= 0; --k) {
+      __syncthreads();
+      if (threadIdx.x == 0) w[k] = w[k] / G[(size_t)k * ld + k];
+      __syncthreads();
+      const double wk = w[k];
+      for (int i = threadIdx.x; i < k; i += 256) w[i] = fma(-G[(size_t)k * ld + i], wk, w[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 256) alpha[i] = w[i];
+  }
+}
+
+// a10 gradient (GPI.py:1046-1051): out[k] = 0.5 tr((alpha alpha^T - Kinv) dK/dtheta_k) for theta = (log c, log ell, log noise)
+// with scikit-learn's kernel gradients: c R, c R d^2 / ell^2, noise I  (R_ij = exp(-0.5 d^2 / ell^2)).
+__global__ __launch_bounds__(256) void k_lml_grad(const double* __restrict__ x, const double* __restrict__ alpha,
+                                                  const double* __restrict__ Kinv, int T, double c, double ell,
+                                                  double noise, double* __restrict__ out) {
+  __shared__ double red[3][256];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const long tt = (long)T * T;
+  for (long idx = threadIdx.x; idx < tt; idx += 256) {
+    const int i = (int)(idx / T), j = (int)(idx % T);
+    const double t = alpha[i] * alpha[j] - Kinv[idx];
+    const double u = x[i] / ell - x[j] / ell, d2 = u * u;
+    const double cr = c * exp(-0.5 * d2);
+    s0 = fma(t, cr, s0);
+    s1 = fma(t, cr * d2, s1);
+    if (i == j) s2 += t;
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  red[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = 0.5 * red[0][0];
+    out[1] = 0.5 * red[1][0];
+    out[2] = 0.5 * noise * red[2][0];
+  }
 }
 
 // ------------------------------------------------------------------ per-cluster operators (plan)
@@ -2676,7 +2720,22 @@ int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const 
 int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, double* out, void* stream) {
   if (!G || !y || !out || T <= 0 || ld < T) return -1;
   if (T > 2048) return -2;
-  hipLaunchKernelGGL(k_trsv_lower_quad, dim3(1), dim3(256), sizeof(double) * T, (hipStream_t)stream, G, ld, y, T, out);
+  hipLaunchKernelGGL(k_trsv_lower_quad, dim3(1), dim3(256), sizeof(double) * T, (hipStream_t)stream, G, ld, y, T, out,
+                     (double*)nullptr);
+  return launch_status();
+}
+
+int hgp_trsv_lower_solve_f64(const double* G, int ld, const double* y, int T, double* alpha, double* quad, void* stream) {
+  if (!G || !y || !alpha || T <= 0 || ld < T) return -1;
+  if (T > 2048) return -2;
+  hipLaunchKernelGGL(k_trsv_lower_quad, dim3(1), dim3(256), sizeof(double) * T, (hipStream_t)stream, G, ld, y, T, quad, alpha);
+  return launch_status();
+}
+
+int hgp_lml_grad_f64(const double* x, const double* alpha, const double* Kinv, int T, double c, double ell, double noise,
+                     double* out3, void* stream) {
+  if (!x || !alpha || !Kinv || !out3 || T <= 0 || !(ell > 0.0)) return -1;
+  hipLaunchKernelGGL(k_lml_grad, dim3(1), dim3(256), 0, (hipStream_t)stream, x, alpha, Kinv, T, c, ell, noise, out3);
   return launch_status();
 }
 

@@ -367,3 +367,22 @@ def trsv_lower_quad(G, y):
     out = torch.empty(1, dtype=torch.float64, device=G.device)
     _ffi.check(_ffi.lib.hgp_trsv_lower_quad_f64(_ptr(G), G.shape[1], _ptr(y), y.numel(), _ptr(out), _stream()), "trsv_lower_quad")
     return out[0]
+
+
+def trsv_lower_solve(G, y):
+    """alpha = tril(G)^{-T} tril(G)^{-1} y and || tril(G)^{-1} y ||^2  (the reference's cho_solve((K, True), y), GPI.py:1043)."""
+    G, y = _dev64(G, "G"), _dev64(y.reshape(-1), "y")
+    alpha = torch.empty_like(y)
+    quad = torch.empty(1, dtype=torch.float64, device=G.device)
+    _ffi.check(_ffi.lib.hgp_trsv_lower_solve_f64(_ptr(G), G.shape[1], _ptr(y), y.numel(), _ptr(alpha), _ptr(quad), _stream()),
+               "trsv_lower_solve")
+    return alpha, quad[0]
+
+
+def lml_grad(x, alpha, Kinv, c, ell, noise):
+    """a10 gradient w.r.t. (log c, log ell, log noise): 0.5 tr((alpha alpha^T - Kinv) dK/dtheta)  (GPI.py:1046-1051)."""
+    x, alpha, Kinv = _dev64(x.reshape(-1), "x"), _dev64(alpha.reshape(-1), "alpha"), _dev64(Kinv, "Kinv")
+    out = torch.empty(3, dtype=torch.float64, device=x.device)
+    _ffi.check(_ffi.lib.hgp_lml_grad_f64(_ptr(x), _ptr(alpha), _ptr(Kinv), x.numel(), float(c), float(ell), float(noise), _ptr(out),
+                                         _stream()), "lml_grad")
+    return out

@@ -196,6 +196,13 @@ int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const 
  * log_marginal_likelihood as written passes K itself as the "factor" to cho_solve (GPI.py:1043); this reproduces
  * that call with G = tril(K).  out[1]. */
 int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, double* out, void* stream);
+/* a10, the same call in full: alpha[T] = G^{-T} G^{-1} y  (= scipy cho_solve((G, True), y) with G = tril(K), GPI.py:1043);
+ * quad[1] = || G^{-1} y ||^2 (may be NULL). */
+int hgp_trsv_lower_solve_f64(const double* G, int ld, const double* y, int T, double* alpha, double* quad, void* stream);
+/* a10 gradient (GPI.py:1046-1051): out3[k] = 0.5 tr((alpha alpha^T - Kinv) dK/dtheta_k), theta = (log c, log ell, log noise),
+ * with scikit-learn's kernel gradients (ConstantKernel * RBF: c R and c R d^2/ell^2; WhiteKernel: noise I). */
+int hgp_lml_grad_f64(const double* x, const double* alpha, const double* Kinv, int T, double c, double ell, double noise,
+                     double* out3, void* stream);
 
 #ifdef __cplusplus
 }

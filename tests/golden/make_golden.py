@@ -261,6 +261,10 @@ def gen_lml():
         val = gp.log_marginal_likelihood(torch.from_numpy(xb), torch.from_numpy(y), None, theta=k.theta)
         out[f"c{i}_theta"], out[f"c{i}_x"], out[f"c{i}_y"] = np.array([c, ell, noise]), xb[:, 0], y[:, 0]
         out[f"c{i}_lml"] = np.array(float(np.asarray(val).reshape(-1)[0]))
+        # value + gradient w.r.t. the log-parameters (GPI.py:1046-1051)
+        val2, grad = gp.log_marginal_likelihood(torch.from_numpy(xb), torch.from_numpy(y), None, theta=k.theta, eval_gradient=True)
+        assert abs(float(np.asarray(val2).reshape(-1)[0]) - float(out[f"c{i}_lml"])) < 1e-9 * abs(float(out[f"c{i}_lml"]))
+        out[f"c{i}_grad"] = np.asarray(grad, dtype=np.float64).reshape(-1)
     out["n_cases"] = np.array(3)
     np.savez_compressed(os.path.join(OUT, "lml.npz"), **out)
 

@@ -92,6 +92,16 @@ def test_lml_a10_golden():
         v2 = gp.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], None, faithful=False)
         ref2 = orc.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], (c, ell, noise), faithful=False)
         assert abs(v2 - ref2) <= 1e-8 * abs(ref2)
+        # value + gradient w.r.t. the log-parameters, as the reference forms it (GPI.py:1046-1051)
+        theta = np.log([c, ell, noise])
+        v3, grad = gp.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], None, theta=theta, eval_gradient=True)
+        assert abs(v3 - float(g[f"c{i}_lml"])) <= 1e-8 * abs(float(g[f"c{i}_lml"]))
+        assert np.allclose(grad, g[f"c{i}_grad"], rtol=1e-7, atol=0.0)
+        v4, grad4 = gp.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], None, theta=theta, eval_gradient=True, faithful=False)
+        ref4, gref4 = orc.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], (c, ell, noise), faithful=False, eval_gradient=True)
+        assert abs(v4 - ref4) <= 1e-8 * abs(ref4) and np.allclose(grad4, gref4, rtol=1e-7, atol=1e-9)
+        with pytest.raises(ValueError):
+            gp.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], None, eval_gradient=True)
 
 
 def test_warp_prior_a11_golden():

@@ -100,6 +100,11 @@ def test_lml_a10():
     for i in range(int(g["n_cases"])):
         v = orc.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], tuple(g[f"c{i}_theta"]), faithful=True)
         assert abs(v - float(g[f"c{i}_lml"])) <= 1e-9 * abs(float(g[f"c{i}_lml"]))
+        # value + gradient w.r.t. (log c, log ell, log noise), GPI.py:1046-1051
+        v2, grad = orc.log_marginal_likelihood(g[f"c{i}_x"], g[f"c{i}_y"], tuple(g[f"c{i}_theta"]), faithful=True,
+                                               eval_gradient=True)
+        assert v2 == v
+        assert np.allclose(grad, g[f"c{i}_grad"], rtol=1e-9, atol=0.0)
 
 
 def test_warp_prior_a11():
