@@ -3,7 +3,7 @@ error behaviour); all arithmetic runs in HIP kernels through hdpgpc_amd.ops.
 
 Built: the kernel object (scikit-learn's ConstantKernel*RBF + WhiteKernel, GPI_HDP.py:164-166),
 IterativeGaussianProcess.pred_dist (GPI.py:457-503), pred_latent_dist (GPI.py:505-560),
-log_marginal_likelihood (GPI.py:976-1056, value only).  Not built here: posterior / backward (the LDS recursion,
+log_marginal_likelihood (GPI.py:976-1056, value and gradient).  Not built here: posterior / backward (the LDS recursion,
 SURVEY.md 8f-1) and fit_torch (gpytorch, 8f-2).
 """
 import math
