@@ -60,6 +60,7 @@ struct PotrfArgs {
   double* logdet;
   int32_t* info;
   int inv_info = 0;   // k_wave_inv also reports info (used when no in-place factor follows)
+  int symmetric = 0;  // the caller guarantees A == A^T bit for bit: only the upper tiles are read
 };
 
 template <int NB>
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_inv(PotrfArgs a) {
   const double* A = a.A + (size_t)m * T * T;
   d4 U[NB * (NB + 1) / 2];
   d4 R[NB];
-  load_sym_upper<NB>(U, A, T, T, lane, scr);
+  if (a.symmetric) load_upper_only<NB>(U, A, T, T, lane);
+  else load_sym_upper<NB>(U, A, T, T, lane, scr);
   {
     double sh = a.add;
     if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(diag_abs_mean<NB>(U, T, lane, a.add), F64_EPS);
@@ -540,6 +542,8 @@ int launch_gemm(const GemmArgs& a, int batch, hipStream_t st) {
   const int nt = ((a.M + 15) / 16) * ((a.N + 15) / 16);
   if (a.Kd <= 96 && a.Kd > 32)
     hipLaunchKernelGGL(k_gemm<24>, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
+  else if (a.Kd <= 128 && a.Kd > 96)
+    hipLaunchKernelGGL(k_gemm<32>, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
   else
     hipLaunchKernelGGL(k_gemm<8>, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
   return launch_status();
@@ -2505,6 +2509,7 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   // Z = chol(K~)^{-1}  (the factor itself is not needed)
   PotrfArgs fa{p->d_A, TP, K, 0.0, 0.0, p->d_Z, nullptr, info};
   fa.inv_info = 1;
+  fa.symmetric = 1;   // k_prep_build writes K~ from (x_i - x_j)^2: exactly symmetric
   switch (p->NB) {
     case 2: launch_wave_inv<2>(fa, st); break;
     case 4: launch_wave_inv<4>(fa, st); break;
