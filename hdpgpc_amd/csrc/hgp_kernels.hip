@@ -1055,6 +1055,152 @@ __global__ __launch_bounds__(256) void k_lml_grad(const double* __restrict__ x, 
   }
 }
 
+// ------------------------------------------------------------------ messages of the switching variable
+// GPI_HDP.forward / backward / coupled_state_coef (GPI_HDP.py:3546-3700) on the device, so that the [N, K] score matrix
+// never leaves HBM between evaluation and assignment.  Sequential in N, K <= 64 states: one wave per direction, lane i
+// = state i, its row of the (clamped, max-shifted) transition matrix in LDS, the message vector broadcast through LDS.
+__device__ __forceinline__ double hmm_exp(double x, double m) {   // the reference's safe_exp element: NaN -> 1e-8
+  const double e = exp(x - m);
+  return (e != e) ? 1e-8 : e;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+struct HmmArgs {
+  const double* q;          // [N,K] log-observations
+  const double* log_pi;     // [K]
+  const double* log_trans;  // [K,K]
+  int N, K;
+  double* fmsg;             // [N,K]
+  double* marg;             // [N]
+  double* bmsg;             // [N,K]
+};
+
+__global__ __launch_bounds__(64) void k_hmm_messages(HmmArgs a) {
+  extern __shared__ double sm[];
+  const int K = a.K, N = a.N, i = threadIdx.x, LD = K + 1;
+  double* P = sm;            // [K][K+1]
+  double* f = P + K * LD;    // [K]
+  const bool fwd = blockIdx.x == 0;
+  const bool live = i < K;
+  const double ninf = -__builtin_inf();
+  // my row of the transition operator: forward uses safe_exp(log_trans^T) clamped at 1e-6, backward safe_exp(log_trans)
+  // clamped at 1e-5 (GPI_HDP.py:3586-3589, 3637-3642)
+  if (live) {
+    double m = ninf;
+    for (int j = 0; j < K; ++j) m = fmax(m, fwd ? a.log_trans[(size_t)j * K + i] : a.log_trans[(size_t)i * K + j]);
+    for (int j = 0; j < K; ++j) {
+      double e = hmm_exp(fwd ? a.log_trans[(size_t)j * K + i] : a.log_trans[(size_t)i * K + j], m);
+      if (e < (fwd ? 1e-6 : 1e-5)) e += 1e-4;
+      P[i * LD + j] = e;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (fwd) {
+    double pi_ = live ? exp(a.log_pi[i]) : 0.0;
+    if (live && pi_ < 1e-10) pi_ += 1e-4;
+    for (int t0 = 0; t0 < N; t0 += 8) {   // the observations of 8 steps are requested together: one load latency per 8 steps
+      double qv8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) qv8[u] = (live && t0 + u < N) ? a.q[(size_t)(t0 + u) * K + i] : ninf;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u;
+        if (t >= N) break;
+        const double qv = qv8[u];
+        const double qm = wave_max(qv);                     // (all 64 lanes take part in the shuffles)
+        const double qe = live ? hmm_exp(qv, qm) : 0.0;
+        double g = pi_;
+        if (t > 0) {
+          g = 0.0;
+          if (live)
+            for (int j = 0; j < K; ++j) g = fma(P[i * LD + j], f[j], g);
+        }
+        const double v = live ? g * qe : 0.0;
+        const double mg = wave_sum(v);
+        const double fi = v / mg;
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+          f[i] = fi;
+          a.fmsg[(size_t)t * K + i] = fi;
+        }
+        if (i == 0) a.marg[t] = mg;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else {
+    double b = 1.0;
+    if (live) a.bmsg[(size_t)(N - 1) * K + i] = 1.0;
+    for (int t0 = N - 2; t0 >= 0; t0 -= 8) {
+      double qv8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) qv8[u] = (live && t0 - u >= 0) ? a.q[(size_t)(t0 - u + 1) * K + i] : ninf;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 - u;
+        if (t < 0) break;
+        const double qv = qv8[u];
+        const double qm = wave_max(qv);
+        const double qe = live ? hmm_exp(qv, qm) : 0.0;
+        if (live) f[i] = b * qe;
+        __builtin_amdgcn_wave_barrier();
+        double v = 0.0;
+        if (live)
+          for (int j = 0; j < K; ++j) v = fma(P[i * LD + j], f[j], v);
+        const double nrm = wave_sum((live && i < K - 1) ? v : 0.0);   // the reference leaves the last state out (:3645)
+        b = v / nrm;
+        if (live) a.bmsg[(size_t)t * K + i] = b;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
+// log of the normalised pair responsibilities (coupled_state_coef): one workgroup per step t
+__global__ __launch_bounds__(256) void k_hmm_pair(const double* __restrict__ q, const double* __restrict__ log_trans,
+                                                  const double* __restrict__ alpha, const double* __restrict__ beta, int N,
+                                                  int K, double* __restrict__ out) {
+  extern __shared__ double sm[];
+  double* soft = sm;          // [K]  safe_exp(q[t]) * beta[t]
+  double* rmax = soft + K;    // [K]  row maxima of log_trans
+  __shared__ double red[256];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  double* o = out + (size_t)t * K * K;
+  if (t == 0) {               // respPair[0] = 0 -> log 0
+    for (int e = tid; e < K * K; e += 256) o[e] = -__builtin_inf();
+    return;
+  }
+  double qm = -__builtin_inf();
+  for (int j = 0; j < K; ++j) qm = fmax(qm, q[(size_t)t * K + j]);
+  for (int j = tid; j < K; j += 256) {
+    soft[j] = hmm_exp(q[(size_t)t * K + j], qm) * beta[(size_t)t * K + j];
+    double m = -__builtin_inf();
+    for (int l = 0; l < K; ++l) m = fmax(m, log_trans[(size_t)j * K + l]);
+    rmax[j] = m;
+  }
+  __syncthreads();
+  double s = 0.0;
+  for (int e = tid; e < K * K; e += 256) {
+    const int i = e / K, j = e % K;
+    s += alpha[(size_t)(t - 1) * K + i] * soft[j] * hmm_exp(log_trans[e], rmax[i]);
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  double den = red[0];
+  if (den == 0.0) den = 1e-10;
+  for (int e = tid; e < K * K; e += 256) {
+    const int i = e / K, j = e % K;
+    o[e] = log(alpha[(size_t)(t - 1) * K + i] * soft[j] * hmm_exp(log_trans[e], rmax[i]) / den);
+  }
+}
+
 // ------------------------------------------------------------------ per-cluster operators (plan)
 // scal[k*8 + ..] : 0 c, 1 ell, 2 noise, 3 iso flag, 4 mean(diag Sigma), 5 jitter of K~, 6 ||K~^{-1}||_inf
 struct PrepArgs {
@@ -2727,6 +2873,20 @@ int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, dou
   if (T > 2048) return -2;
   hipLaunchKernelGGL(k_trsv_lower_quad, dim3(1), dim3(256), sizeof(double) * T, (hipStream_t)stream, G, ld, y, T, out,
                      (double*)nullptr);
+  return launch_status();
+}
+
+int hgp_hmm_messages_f64(const double* q, const double* log_pi, const double* log_trans, int N, int K, double* fmsg,
+                         double* marg, double* bmsg, double* log_resp_pair, void* stream) {
+  if (N == 0) return 0;
+  if (!q || !log_pi || !log_trans || !fmsg || !marg || !bmsg || N < 0 || K <= 0) return -1;
+  if (K > 64) return -2;
+  HmmArgs a{q, log_pi, log_trans, N, K, fmsg, marg, bmsg};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_hmm_messages, dim3(2), dim3(64), sizeof(double) * ((size_t)K * (K + 1) + K), st, a);
+  if (log_resp_pair)
+    hipLaunchKernelGGL(k_hmm_pair, dim3(N), dim3(256), sizeof(double) * 2 * K, st, q, log_trans, (const double*)fmsg,
+                       (const double*)bmsg, N, K, log_resp_pair);
   return launch_status();
 }
 

@@ -386,3 +386,18 @@ def lml_grad(x, alpha, Kinv, c, ell, noise):
     _ffi.check(_ffi.lib.hgp_lml_grad_f64(_ptr(x), _ptr(alpha), _ptr(Kinv), x.numel(), float(c), float(ell), float(noise), _ptr(out),
                                          _stream()), "lml_grad")
     return out
+
+
+
+def hmm_messages(q, log_pi, log_trans, want_pair=True):
+    """forward / backward messages of the switching variable and the log pair responsibilities
+    (GPI_HDP.forward, backward, coupled_state_coef).  q [N,K] log-observations; returns (fmsg, marg, bmsg, log_resp_pair)."""
+    q, log_pi, log_trans = _dev64(q, "q"), _dev64(log_pi.reshape(-1), "log_pi"), _dev64(log_trans, "log_trans")
+    N, K = q.shape
+    fmsg = torch.empty((N, K), dtype=torch.float64, device=q.device)
+    marg = torch.empty(N, dtype=torch.float64, device=q.device)
+    bmsg = torch.empty((N, K), dtype=torch.float64, device=q.device)
+    pair = torch.empty((N, K, K), dtype=torch.float64, device=q.device) if want_pair else None
+    _ffi.check(_ffi.lib.hgp_hmm_messages_f64(_ptr(q), _ptr(log_pi), _ptr(log_trans), N, K, _ptr(fmsg), _ptr(marg), _ptr(bmsg),
+                                             _ptr(pair), _stream()), "hmm_messages")
+    return fmsg, marg, bmsg, pair

@@ -196,6 +196,13 @@ int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const 
  * log_marginal_likelihood as written passes K itself as the "factor" to cho_solve (GPI.py:1043); this reproduces
  * that call with G = tril(K).  out[1]. */
 int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, double* out, void* stream);
+/* SURVEY 8f-3 - messages of the switching variable on the device (GPI_HDP.forward / backward / coupled_state_coef,
+ * GPI_HDP.py:3546-3700), full recursion.  q[N,K]: log-observations (the [N,K] score matrix after LogLik); log_pi[K] =
+ * compute_trans_pi, log_trans[K,K] = compute_trans_A (both stay host-side control plane).  Outputs: fmsg[N,K],
+ * marg[N] (forward messages and their normalisers), bmsg[N,K] (backward messages, normalised without the last state as
+ * in GPI_HDP.py:3645), log_resp_pair[N,K,K] (may be NULL; row 0 = -inf as in the reference).  K <= 64 (-2 above). */
+int hgp_hmm_messages_f64(const double* q, const double* log_pi, const double* log_trans, int N, int K, double* fmsg,
+                         double* marg, double* bmsg, double* log_resp_pair, void* stream);
 /* a10, the same call in full: alpha[T] = G^{-T} G^{-1} y  (= scipy cho_solve((G, True), y) with G = tril(K), GPI.py:1043);
  * quad[1] = || G^{-1} y ||^2 (may be NULL). */
 int hgp_trsv_lower_solve_f64(const double* G, int ld, const double* y, int T, double* alpha, double* quad, void* stream);

@@ -328,6 +328,38 @@ def gen_offline(tag, rec, n, stride):
         out[f"m{m}_free_deg"] = np.array(float(g.free_deg_MNIV))
     out["q"] = np.stack(qs, axis=1)
     np.savez_compressed(os.path.join(OUT, f"offline_{tag}.npz"), **out)
+    # forward / backward messages and pair responsibilities of the switching variable on the run's final
+    # variational observations q (GPI_HDP.py:3546-3700), full recursion (no cached prefix)
+    rec = {}
+    of, ob, oc = sw.forward, sw.backward, sw.coupled_state_coef
+
+    def f_(pi=None, trans_A=None, q=None):
+        out_ = of(pi, trans_A, q)
+        rec["f"] = (pi, q, out_)
+        return out_
+
+    def b_(trans_A=None, q=None, margprob=None):
+        out_ = ob(trans_A, q, margprob)
+        rec["b"] = out_
+        return out_
+
+    def c_(alpha=None, beta=None, trans_A=None, q=None, margprobs=None):
+        out_ = oc(alpha, beta, trans_A, q, margprobs)
+        rec["c"] = out_
+        return out_
+
+    sw.forward, sw.backward, sw.coupled_state_coef = f_, b_, c_
+    keep = sw.fmsg, sw.margPrObs
+    sw.fmsg = None
+    sw.variational_local_terms(sw.q[-1])        # the reference's own call sequence (GPI_HDP.py:586-628)
+    sw.fmsg, sw.margPrObs = keep
+    sw.forward, sw.backward, sw.coupled_state_coef = of, ob, oc
+    pi_in, q_in, (fmsg, marg) = rec["f"]
+    K = q_in.shape[1]
+    hm = {"q": npy(q_in), "log_pi": npy(sw.compute_trans_pi(K, pi_in)), "log_trans": npy(sw.compute_trans_A(K)),
+          "fmsg": npy(fmsg), "margPrObs": npy(marg), "bmsg": npy(rec["b"]), "log_respPair": npy(rec["c"])}
+    np.savez_compressed(os.path.join(OUT, f"hmm_{tag}.npz"), **hm)
+    print(f"hmm_{tag}: q{hm['q'].shape} log_trans{hm['log_trans'].shape}")
     print(f"offline_{tag}: N={N} T={T} M={len(models)} counts={[len(g.indexes) for g in models]}")
 
 

@@ -259,3 +259,32 @@ def test_rts_chain_kernel_matches_the_sequential_recursion(T, n):
         Cr[t] = Cr[t] + J[t] @ (Cr[t + 1] - P[t]) @ J[t].T
     assert np.allclose(Mg.cpu().numpy(), Mr, rtol=1e-11, atol=1e-11)
     assert np.allclose(Cg.cpu().numpy(), Cr, rtol=1e-11, atol=1e-11)
+
+
+def test_hmm_messages_8f3_golden_and_large():
+    """hgp_hmm_messages_f64 against the reference's forward / backward / coupled_state_coef outputs (record-102 run),
+    then against the oracle on a long synthetic chain (N = 2 272, K = 9) with -inf entries as birth proposals leave them."""
+    g = golden("hmm_r102_t45.npz")
+    f, m, b, c = ops.hmm_messages(dev(g["q"]), dev(g["log_pi"]), dev(g["log_trans"]))
+    assert np.allclose(f.cpu().numpy(), g["fmsg"], rtol=1e-11, atol=1e-300)
+    assert np.allclose(m.cpu().numpy(), g["margPrObs"], rtol=1e-11, atol=0)
+    assert np.allclose(b.cpu().numpy(), g["bmsg"], rtol=1e-11, atol=1e-300)
+    cr, cg = g["log_respPair"], c.cpu().numpy()
+    fin = np.isfinite(cr)
+    assert np.array_equal(np.isfinite(cg), fin) and np.allclose(cg[fin], cr[fin], rtol=1e-10, atol=1e-10)
+    assert np.array_equal(np.argmax(f.cpu().numpy() * b.cpu().numpy(), axis=1), np.argmax(g["fmsg"] * g["bmsg"], axis=1))
+    rng = np.random.default_rng(9)
+    N, K = 2272, 9
+    q = rng.normal(size=(N, K)) * 30 - 100
+    lt = np.log(rng.dirichlet(np.ones(K) * 0.3, size=K))
+    lt[:, -1] = -np.inf                                   # a state nobody has entered yet (compute_trans_A pads with -inf)
+    lp = np.log(rng.dirichlet(np.ones(K)))
+    f, m, b, c = ops.hmm_messages(dev(q), dev(lp), dev(lt))
+    fr, mr = orc.hmm_forward(q, lp, lt)
+    br = orc.hmm_backward(q, lt)
+    assert np.allclose(f.cpu().numpy(), fr, rtol=1e-9, atol=1e-300) and np.allclose(m.cpu().numpy(), mr, rtol=1e-9, atol=0)
+    assert np.allclose(b.cpu().numpy(), br, rtol=1e-9, atol=1e-300)
+    cr = orc.hmm_pair_coef(fr, br, q, lt)
+    fin = np.isfinite(cr)
+    cg = c.cpu().numpy()
+    assert np.array_equal(np.isfinite(cg), fin) and np.allclose(cg[fin], cr[fin], rtol=1e-8, atol=1e-8)

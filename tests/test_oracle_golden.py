@@ -131,3 +131,16 @@ def test_offline_trace_assignments():
     assert rel_err(q, g["q"]) < RTOL
     # each beat's own cluster scores it best among the clusters it was assigned from
     assert np.array_equal(np.argmax(q, axis=1) == g["resp_assigned"], np.argmax(g["q"], axis=1) == g["resp_assigned"])
+
+
+def test_hmm_messages_8f3():
+    """forward / backward / coupled_state_coef of the switching variable (GPI_HDP.py:3546-3700) on the final
+    variational observations of the record-102 run."""
+    g = golden("hmm_r102_t45.npz")
+    f, m = orc.hmm_forward(g["q"], g["log_pi"], g["log_trans"])
+    b = orc.hmm_backward(g["q"], g["log_trans"])
+    c = orc.hmm_pair_coef(g["fmsg"], g["bmsg"], g["q"], g["log_trans"])
+    assert np.allclose(f, g["fmsg"], rtol=1e-12, atol=0) and np.allclose(m, g["margPrObs"], rtol=1e-12, atol=0)
+    assert np.allclose(b, g["bmsg"], rtol=1e-12, atol=0)
+    fin = np.isfinite(g["log_respPair"])
+    assert np.array_equal(np.isfinite(c), fin) and np.allclose(c[fin], g["log_respPair"][fin], rtol=1e-12, atol=0)

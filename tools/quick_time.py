@@ -72,3 +72,10 @@ for (b, T) in [(2272, 90), (256, 90), (16, 90), (1024, 128)]:
     M = dev(rng.normal(size=(b, T, T))); m0 = dev(np.eye(T)); sc = dev(G[0])
     t = timeit(lambda: ops.mniw_loglik(M, Gam, m0, None, sc), n=3, w=1)
     print(f"mniw_loglik (a9) b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} evals/s", flush=True)
+
+# switching-variable messages (forward + backward + pair responsibilities), sequential in N
+for (N, K) in [(2272, 3), (2272, 9), (32768, 16), (32768, 64)]:
+    rng = np.random.default_rng(2)
+    q = dev(rng.normal(size=(N, K)) * 30 - 100); lt = dev(np.log(rng.dirichlet(np.ones(K), size=K))); lp = dev(np.log(rng.dirichlet(np.ones(K))))
+    t = timeit(lambda: ops.hmm_messages(q, lp, lt), n=3, w=1)
+    print(f"hmm_messages N={N} K={K}: {t*1e3:.3f} ms ({t/N*1e9:.0f} ns per step)", flush=True)
