@@ -188,3 +188,23 @@ def test_large_T_not_positive_definite_is_reported_per_pair():
     assert (info[:, 0] == 0).all() and (info[:, 1] > 0).all()
     _, q_ref, _ = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"][:1], b["mean"][:1], b["Sigma"][:1])
     assert rel_err(quad[:, 0].cpu().numpy(), q_ref[:, 0]) < 1e-8
+
+
+@pytest.mark.parametrize("N,K", [(1, 1), (1, 5), (2, 1), (17, 64), (0, 4)])
+def test_hmm_messages_edge_sizes(N, K):
+    """hgp_hmm_messages_f64: single step, single state, the 64-state limit, the empty batch; 65 states is refused (-2)."""
+    rng = np.random.default_rng(N * 100 + K)
+    q = rng.normal(size=(N, K)) * 5 - 20
+    lt = np.log(rng.dirichlet(np.ones(K), size=K)) if K > 1 else np.zeros((1, 1))
+    lp = np.log(rng.dirichlet(np.ones(K))) if K > 1 else np.zeros(1)
+    f, m, b, c = ops.hmm_messages(dev(q), dev(lp), dev(lt))
+    if N == 0:
+        assert f.shape == (0, K)
+        return
+    fr, mr = orc.hmm_forward(q, lp, lt)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        br = orc.hmm_backward(q, lt)
+    assert np.allclose(f.cpu().numpy(), fr, rtol=1e-10, atol=1e-300) and np.allclose(m.cpu().numpy(), mr, rtol=1e-10)
+    assert np.allclose(b.cpu().numpy(), br, rtol=1e-10, atol=1e-300, equal_nan=True)
+    z = ctypes.c_void_p(16)
+    assert _ffi.lib.hgp_hmm_messages_f64(z, z, z, 3, 65, z, z, z, None, None) == -2
