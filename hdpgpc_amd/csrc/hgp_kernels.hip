@@ -1063,33 +1063,6 @@ __device__ __forceinline__ double hmm_exp(double x, double m) {   // the referen
   const double e = exp(x - m);
   return (e != e) ? 1e-8 : e;
 }
-// All-reduce over the 64 lanes without the LDS crossbar: inside each row of 16 lanes by DPP rotations (row_ror 8, 4, 2,
-// 1: after the four steps every lane holds its row's result), across the four rows with the gfx950 permlane swaps.
-// About 25 VALU instructions against 12 ds_bpermute round trips for the shuffle butterfly (0.77 -> 0.51 us per step).
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-template <bool MAX>
-__device__ __forceinline__ double wave_allreduce(double v) {
-  auto op = [](double a, double b) { return MAX ? fmax(a, b) : a + b; };
-  v = op(v, dpp_f64<0x128>(v));   // row_ror:8
-  v = op(v, dpp_f64<0x124>(v));   // row_ror:4
-  v = op(v, dpp_f64<0x122>(v));   // row_ror:2
-  v = op(v, dpp_f64<0x121>(v));   // row_ror:1
-  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  v = op(__hiloint2double((int)b[0], (int)a[0]), __hiloint2double((int)b[1], (int)a[1]));
-  lo = (unsigned)__double2loint(v);
-  hi = (unsigned)__double2hiint(v);
-  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return op(__hiloint2double((int)b[0], (int)a[0]), __hiloint2double((int)b[1], (int)a[1]));
-}
-
 struct HmmArgs {
   const double* q;          // [N,K] log-observations
   const double* log_pi;     // [K]
