@@ -418,12 +418,14 @@ class GPI_model:
                                torch.stack((eye if mi.m_r_cov is None else mi.m_r_cov, eye if mo.m_r_cov is None else mo.m_r_cov)),
                                torch.stack((mi.scale, mo.scale)))).contiguous()
         ch["ws"] = torch.empty(6 * T * T + 2 * T, dtype=f64, device=dev)     # gathered previous state (hgp_lds_chain_gather_f64)
-        ch["X4"] = torch.empty((4, T, T), dtype=f64, device=dev)             # input of the batched inverse of a step
+        ch["X5"] = torch.empty((5, T, T), dtype=f64, device=dev)             # Kalman P_k + the 4 inputs of the batched inverse
+        ch["y1s"] = torch.zeros((2, T, 1), dtype=f64, device=dev)            # (f_post, y) of the MNIW updates
+        ch["y2s"] = torch.zeros((2, T, 1), dtype=f64, device=dev)            # (f_sm_prev, f_post)
         ch["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
         ch["sync"] = torch.zeros(1, dtype=torch.int32, device=dev)           # inter-block counter of hgp_lds_chain_finish_f64
         return ch
 
-    def _chain_step(self, ch, y):
+    def _chain_step(self, ch):
         """One member (N >= 2 after it): include_sample + backwards_pair + bayesian_new_params on the stacks.
 
         (Measured: running the three branches that only read the previous state - Kalman update, smoother gain, first
@@ -434,40 +436,42 @@ class GPI_model:
         T = eye.shape[0]
         tt = T * T
         pos = ch["pos"]
-        ws = ops.lds_chain_gather(ch["A"], ch["G"], ch["C"], ch["S"], ch["P"], ch["Psm"], ch["F"], ch["Fsm"], pos, ch["ws"])
-        A, G, C, S, c0, Psm = (ws[i * tt:(i + 1) * tt].view(T, T) for i in range(6))
+        y1s, y2s, X5 = ch["y1s"], ch["y2s"], ch["X5"]
+        ws = ops.lds_chain_gather(ch["A"], ch["G"], ch["C"], ch["S"], ch["Psm"], ch["P"], ch["F"], ch["Fsm"], pos, ch["ws"],
+                                  Y=ch["Y"], y_row0=ch["y_row0"], y_out=y1s[1])
+        A, G, C, S, Psm, c0 = (ws[i * tt:(i + 1) * tt].view(T, T) for i in range(6))
         m0, Fsm = ws[6 * tt:6 * tt + T].view(T, 1), ws[6 * tt + T:].view(T, 1)   # filtered / smoothed mean of the previous step
+        y = y1s[1]                                                              # the member's observation
         n0 = ch["n0"]
         means, Rs, scales = ch["W"][0], ch["W"][1], ch["W"][2]
         # The three factorisations that only need the previous state go out as ONE batch of 4 single-matrix inverses
-        # (a 90 x 90 inverse is latency-bound: 50 us whether the launch carries one matrix or four): S of the Kalman
-        # update, A c0 A^T + G of backwards_pair, and the two MNIW scale matrices.  Additions ride in the GEMM epilogues.
-        X4 = ch["X4"]                                                        # [4,T,T] input of the batched inverse
-        AP = mm(A, torch.stack((Psm, c0)))                                   # A P_sm and A c0 (A shared)
-        PP = mm(AP, A, transB=True, add=G)                                   # predictive covariances of both
-        Pk = PP[0]
-        X4[1].copy_(PP[1])
-        P = X4[1]
+        # (a 90 x 90 inverse is latency-bound: the launch costs the same with one matrix or four): A c0 A^T + G of
+        # backwards_pair, S of the Kalman update, and the two MNIW scale matrices.  X5 = [Pk, P, Sk, R0', R1'] holds the
+        # Kalman predictive covariance followed by the four inverse inputs; additions ride in the GEMM epilogues.
+        AP = mm(A, ws[4 * tt:6 * tt].view(2, T, T))                            # A P_sm and A c0 (A shared)
+        mm(AP, A, transB=True, add=G, out=X5[0:2])                             # predictive covariances of both
+        Pk, P = X5[0], X5[1]
         xm = mm(A, Fsm)
-        f_pred = mm(C, xm)                                                   # pred_dist short-circuits on the shared grid
-        mm(mm(C, Pk), C, transB=True, add=S, out=X4[0])
-        ops.add_diag_mean(Rs, scales, 1e-2, out=X4[2:])
-        Z4, i4 = ops.chol_inverse(X4)
-        self._pending.append(("posterior / backwards_pair", i4[:2]))
+        f_pred = mm(C, xm)                                                     # pred_dist short-circuits on the shared grid
+        mm(mm(C, Pk), C, transB=True, add=S, out=X5[2])
+        ops.add_diag_mean(Rs, scales, 1e-2, out=X5[3:5])
+        Z4, i4 = ops.chol_inverse(X5[1:5])
+        self._pending.append(("backwards_pair / posterior", i4[:2]))
         inv4 = mm(Z4, Z4, transA=True)
         i1, scale_inv = i4[2:], inv4[2:]
         # Kalman update (GPI.py:140-151, Joseph form)
-        K_t = mm(mm(Pk, C, transB=True), inv4[0])
-        f_post = mm(K_t, y - f_pred, add=xm)
+        K_t = mm(mm(Pk, C, transB=True), inv4[1])
+        f_post = mm(K_t, y - f_pred, add=xm, out=y1s[0])
         IKC = mm(K_t, C, alpha=-1.0, add=eye)
         c_post = mm(mm(K_t, S), K_t, transB=True, add=mm(mm(IKC, Pk), IKC, transB=True))
         # backwards_pair on the last two filtered states
-        J = mm(mm(c0, A, transB=True), inv4[1])
-        f_sm_prev = mm(J, f_post - mm(A, m0), add=m0)
+        J = mm(mm(c0, A, transB=True), inv4[0])
+        f_sm_prev = mm(J, f_post - mm(A, m0), add=m0, out=y2s[0])
+        y2s[1].copy_(f_post)
         P_sm_prev = mm(mm(J, c_post - P), J, transB=True, add=c0)
         ops.lds_chain_scatter(f_post, c_post, f_sm_prev, P_sm_prev, ch["F"], ch["Fsm"], ch["P"], ch["Psm"], pos)
-        # bayesian_new_params (one-step MNIW update; on a failed factorisation the previous distributions are kept)
-        y1s, y2s = torch.stack((f_post, y)), torch.stack((f_sm_prev, f_post))
+        # bayesian_new_params (one-step MNIW update; on a failed factorisation the previous distributions are kept):
+        # y1s = (f_post, y), y2s = (f_sm_prev, f_post)
         S__ = mm(y2s, y2s, transB=True, add=scale_inv)
         S_ = mm(y1s, y2s, transB=True, add=mm(means, scale_inv))
         Zs, i2 = ops.chol_inverse(S__, 0.0, 1e-8)
@@ -590,14 +594,10 @@ class GPI_model:
                 self.bayesian_new_params(1.0)
             rest = active[head:]
             ch = self._chain_alloc(len(rest))
-            Yr = (y_trains[rest][..., 0] if y_trains.ndim == 3 else y_trains[rest]).reshape(len(rest), -1, 1).contiguous()
-            k = torch.zeros(1, dtype=torch.int64, device=self.device)
-
-            def step():
-                self._chain_step(ch, Yr.index_select(0, k)[0])
-                k.add_(1)
-
-            self._run_graphed(step, len(rest))
+            # observations of the run; the step reads row (pos - y_row0) inside its gather kernel
+            ch["Y"] = (y_trains[rest][..., 0] if y_trains.ndim == 3 else y_trains[rest]).reshape(len(rest), -1).contiguous()
+            ch["y_row0"] = int(ch["pos"][0])
+            self._run_graphed(lambda: self._chain_step(ch), len(rest))
             self._chain_commit(ch, rest, x_trains, y_trains)
             if int(ch["bad"][0]) != 0 and self.verbose:
                 print("Alg error matrix ill conditioned.")     # GPI_model.py:1069

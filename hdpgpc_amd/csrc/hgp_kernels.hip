@@ -719,12 +719,16 @@ __global__ __launch_bounds__(256) void k_chol_rank1(Rank1Args a) {
 // The captured per-member step (hdpgpc_amd/GPI_model.py: _chain_step) is a chain of small GEMMs and inverses; what sits
 // between them was ~75 element-wise / index launches of 3-5 us each.  Two kernels replace most of them.
 //
-// k_chain_gather: rows `pos` of the eight state stacks -> one contiguous workspace (A, G, C, S, P, Psm [T,T]; F, Fsm [T]).
+// k_chain_gather: rows `pos` of the eight state stacks -> one contiguous workspace (A, G, C, S, Psm, P [T,T]; F, Fsm [T]),
+// and the observation of the member this step includes, Y[pos - y_row0], into y_out.
 struct ChainGatherArgs {
-  const double* st[8];   // A, G, C, S, P, Psm (T*T each), F, Fsm (T each)
+  const double* st[8];   // A, G, C, S, Psm, P (T*T each), F, Fsm (T each)
   const int64_t* pos;
   double* out;           // [6 T T + 2 T]
   int T;
+  const double* Y;       // [n,T] observations of the run (may be NULL)
+  long y_row0;
+  double* y_out;         // [T]
 };
 
 __global__ __launch_bounds__(256) void k_chain_gather(ChainGatherArgs a) {
@@ -742,6 +746,8 @@ __global__ __launch_bounds__(256) void k_chain_gather(ChainGatherArgs a) {
     }
     a.out[i] = v;
   }
+  if (a.Y && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < a.T; i += 256) a.y_out[i] = a.Y[(p - a.y_row0) * a.T + i];
 }
 
 // k_chain_scatter: the new filtered state and the re-smoothed previous one into the stacks (rows pos + 1 and pos).
@@ -2798,11 +2804,11 @@ int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const do
   return launch_status();
 }
 
-int hgp_lds_chain_gather_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stP,
-                             const double* stPsm, const double* stF, const double* stFsm, const int64_t* pos, int T,
-                             double* out, void* stream) {
-  if (!stA || !stG || !stC || !stS || !stP || !stPsm || !stF || !stFsm || !pos || !out || T <= 0) return -1;
-  ChainGatherArgs a{{stA, stG, stC, stS, stP, stPsm, stF, stFsm}, pos, out, T};
+int hgp_lds_chain_gather_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stPsm,
+                             const double* stP, const double* stF, const double* stFsm, const int64_t* pos, int T,
+                             double* out, const double* Y, long y_row0, double* y_out, void* stream) {
+  if (!stA || !stG || !stC || !stS || !stP || !stPsm || !stF || !stFsm || !pos || !out || T <= 0 || (Y && !y_out)) return -1;
+  ChainGatherArgs a{{stA, stG, stC, stS, stPsm, stP, stF, stFsm}, pos, out, T, Y, y_row0, y_out};
   const long total = 6L * T * T + 2L * T;
   hipLaunchKernelGGL(k_chain_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();

@@ -345,11 +345,13 @@ def chol_rank1(L, v, alpha=None, beta=None):
     return (L3 if L.dim() == 3 else L3[0]), info
 
 
-def lds_chain_gather(stA, stG, stC, stS, stP, stPsm, stF, stFsm, pos, out):
-    """8f-1 glue: row pos[0] of the eight state stacks -> out[6 T T + 2 T] (A, G, C, S, P, Psm, F, Fsm)."""
+def lds_chain_gather(stA, stG, stC, stS, stPsm, stP, stF, stFsm, pos, out, Y=None, y_row0=0, y_out=None):
+    """8f-1 glue: row pos[0] of the eight state stacks -> out[6 T T + 2 T] (A, G, C, S, Psm, P, F, Fsm); optionally the
+    observation Y[pos[0] - y_row0] -> y_out."""
     T = stA.shape[1]
-    _ffi.check(_ffi.lib.hgp_lds_chain_gather_f64(_ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(stP), _ptr(stPsm), _ptr(stF),
-                                                 _ptr(stFsm), _ptr(pos), T, _ptr(out), _stream()), "lds_chain_gather")
+    _ffi.check(_ffi.lib.hgp_lds_chain_gather_f64(_ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(stPsm), _ptr(stP), _ptr(stF),
+                                                 _ptr(stFsm), _ptr(pos), T, _ptr(out), _ptr(Y), int(y_row0), _ptr(y_out),
+                                                 _stream()), "lds_chain_gather")
     return out
 
 

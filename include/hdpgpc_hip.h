@@ -157,8 +157,9 @@ int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const do
 
 /* 8f-1 (first "next" row) - glue of one member step of the LDS recursion (GPI_model.full_pass_weighted,
  * GPI_model.py:377-406), fused so that a captured step is GEMMs + inverses + two of these launches.
- * hgp_lds_chain_gather_f64: row pos[0] of the state stacks A, Gamma, C, Sigma, cov_f, cov_f_sm ([L,T,T]) and f_star,
- *   f_star_sm ([L,T]) into out[6 T T + 2 T] in that order (replaces the per-step list indexing of GPI_model.py:300-318).
+ * hgp_lds_chain_gather_f64: row pos[0] of the state stacks A, Gamma, C, Sigma, cov_f_sm, cov_f ([L,T,T]) and f_star,
+ *   f_star_sm ([L,T]) into out[6 T T + 2 T] in that order (replaces the per-step list indexing of GPI_model.py:300-318);
+ *   if Y != NULL also y_out[T] = Y[pos[0] - y_row0] (the observation of the member this step includes).
  * hgp_lds_chain_finish_f64: element-wise tail of the two matrix_normal_inv_wishart.posterior updates
  *   (GPI_model.py:1326-1336; item 0 = internal (A, Gamma), item 1 = observation (C, Sigma)):
  *     bad = any(info1, info2 != 0)                      (then the previous distributions are kept, GPI_model.py:1068-1071)
@@ -168,9 +169,9 @@ int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const do
  *                                                        (bayesian_new_params, GPI_model.py:1076-1106)
  *     W = (means', R', scales') [3,2,T,T];  n0, Nf, bad_count, pos updated in place (pos += 1).
  *     sync: one int32 the caller zero-initialises once (inter-block counter, left at zero). */
-int hgp_lds_chain_gather_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stP,
-                             const double* stPsm, const double* stF, const double* stFsm, const int64_t* pos, int T,
-                             double* out, void* stream);
+int hgp_lds_chain_gather_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stPsm,
+                             const double* stP, const double* stF, const double* stFsm, const int64_t* pos, int T,
+                             double* out, const double* Y, long y_row0, double* y_out, void* stream);
 /* hgp_rts_chain_f64: the sequential part of GPI.backward (GPI.py:240-270) for all n states in one launch, T <= 96
  * (-2 above).  J[n-1,T,T] = c_t A_t^T P_t^{-1}, P[n-1,T,T] = A_t c_t A_t^T + Gamma_t and AM[n-1,T] = A_t m_t come from
  * the FILTERED states (batched by the caller); in place, for t = n-2 .. 0:
