@@ -421,6 +421,7 @@ class GPI_model:
         ch["X5"] = torch.empty((5, T, T), dtype=f64, device=dev)             # Kalman P_k + the 4 inputs of the batched inverse
         ch["y1s"] = torch.zeros((2, T, 1), dtype=f64, device=dev)            # (f_post, y) of the MNIW updates
         ch["y2s"] = torch.zeros((2, T, 1), dtype=f64, device=dev)            # (f_sm_prev, f_post)
+        ch["I0"] = torch.stack((eye, torch.zeros_like(eye))).contiguous()    # addends of the batched (I - K C, -K Sigma)
         ch["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
         ch["sync"] = torch.zeros(1, dtype=torch.int32, device=dev)           # inter-block counter of hgp_lds_chain_finish_f64
         return ch
@@ -451,22 +452,26 @@ class GPI_model:
         AP = mm(A, ws[4 * tt:6 * tt].view(2, T, T))                            # A P_sm and A c0 (A shared)
         mm(AP, A, transB=True, add=G, out=X5[0:2])                             # predictive covariances of both
         Pk, P = X5[0], X5[1]
-        xm = mm(A, Fsm)
+        Amf = mm(A, ws[6 * tt:].view(2, T, 1))                                 # A m0 and A f_sm (A shared)
+        Am0, xm = Amf[0], Amf[1]
         f_pred = mm(C, xm)                                                     # pred_dist short-circuits on the shared grid
-        mm(mm(C, Pk), C, transB=True, add=S, out=X5[2])
+        CPk = mm(C, Pk)
+        mm(CPk, C, transB=True, add=S, out=X5[2])
         ops.add_diag_mean(Rs, scales, 1e-2, out=X5[3:5])
         Z4, i4 = ops.chol_inverse(X5[1:5])
         self._pending.append(("backwards_pair / posterior", i4[:2]))
         inv4 = mm(Z4, Z4, transA=True)
         i1, scale_inv = i4[2:], inv4[2:]
-        # Kalman update (GPI.py:140-151, Joseph form)
-        K_t = mm(mm(Pk, C, transB=True), inv4[1])
+        # Kalman update (GPI.py:140-151, Joseph form).  P C^T is the transpose of the C P already formed for S (P is a
+        # covariance), so the gain is one transposed product: K = (C P)^T S^{-1}.
+        K_t = mm(CPk, inv4[1], transA=True)
         f_post = mm(K_t, y - f_pred, add=xm, out=y1s[0])
-        IKC = mm(K_t, C, alpha=-1.0, add=eye)
-        c_post = mm(mm(K_t, S), K_t, transB=True, add=mm(mm(IKC, Pk), IKC, transB=True))
-        # backwards_pair on the last two filtered states
-        J = mm(mm(c0, A, transB=True), inv4[0])
-        f_sm_prev = mm(J, f_post - mm(A, m0), add=m0, out=y2s[0])
+        KCS = mm(K_t, ws[2 * tt:4 * tt].view(2, T, T), alpha=-1.0, add=ch["I0"])   # (I - K C, -K Sigma) in one launch
+        IKC = KCS[0]
+        c_post = mm(KCS[1], K_t, transB=True, alpha=-1.0, add=mm(mm(IKC, Pk), IKC, transB=True))
+        # backwards_pair on the last two filtered states: J = c0 A^T P^{-1} = (A c0)^T P^{-1}
+        J = mm(AP[1], inv4[0], transA=True)
+        f_sm_prev = mm(J, f_post - Am0, add=m0, out=y2s[0])
         y2s[1].copy_(f_post)
         P_sm_prev = mm(mm(J, c_post - P), J, transB=True, add=c0)
         ops.lds_chain_scatter(f_post, c_post, f_sm_prev, P_sm_prev, ch["F"], ch["Fsm"], ch["P"], ch["Psm"], pos)
