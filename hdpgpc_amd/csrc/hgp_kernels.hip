@@ -1263,6 +1263,7 @@ __global__ __launch_bounds__(256) void k_prep_build(PrepArgs a) {
     sc[3] = redi[0] ? 0.0 : 1.0;
     sc[4] = mS;
     sc[5] = jit;
+    sc[6] = 0.0;   // ||K~^{-1}||_inf: accumulated by k_prep_final with an atomic maximum
   }
   if (k == 0 && blockIdx.y == 0)
     for (int i = tid; i < TP; i += 256) a.xb_copy[i] = (i < T) ? a.xb[i] : 0.0;
@@ -1302,41 +1303,54 @@ __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
   const double* Q = a.Q + (size_t)k * TP * TP;
   const double* Ki = a.Kinv + (size_t)k * TP * TP;
   double* Mp = a.Mp + (size_t)k * TP * TP;
-  // Column order of M' (physical jp -> logical j).  The pairs kernel reads row k of M' as the A operands of the NH
+  // M' = c^2 (sym(Q) - sym(Kinv)) by 32 x 32 tiles: tile (bi, bj) and its mirror (bj, bi) are both read row-wise
+  // (coalesced) and the mirror is transposed through LDS (pitch 33).
+  // Column order of M' (logical j -> physical jp).  The pairs kernel reads row k of M' as the A operands of the NH
   // row tiles of one half h (tiles NH h .. NH h + NH - 1): inside a half, tiles are interleaved two by two so that ONE
   // 16-byte load per lane (lane cc) yields the operands of tiles 2q and 2q + 1; an odd last tile stays contiguous.
-  const int NHh = (TP / 16) / 2;
-  for (int idx = blockIdx.y * 256 + tid; idx < TP * TP; idx += gridDim.y * 256) {
-    int i = idx / TP, jp = idx % TP;
-    const int hh = jp / (16 * NHh), loc = jp % (16 * NHh);
-    int tl, cc;
-    if (!a.interleave) {
-      tl = loc / 16;
-      cc = loc % 16;
-    } else if (loc < 32 * (NHh / 2)) {
-      tl = 2 * (loc / 32) + (loc & 1);
-      cc = (loc % 32) >> 1;
-    } else {
-      tl = NHh - 1;
-      cc = loc - 16 * (NHh - 1);
+  __shared__ double tq[32][33], tk[32][33];
+  const int NHh = (TP / 16) / 2, nt = TP / 32;
+  const int tx = tid & 31, ty = tid >> 5;   // 32 x 8 threads, 4 rows each
+  for (int t = blockIdx.y; t < nt * nt; t += gridDim.y) {
+    const int bi = t / nt, bj = t % nt;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // mirror tile, natural order: element (32 bj + y, 32 bi + tx)
+      const int y = ty + 8 * r;
+      tq[y][tx] = Q[(size_t)(32 * bj + y) * TP + 32 * bi + tx];
+      tk[y][tx] = Ki[(size_t)(32 * bj + y) * TP + 32 * bi + tx];
     }
-    const int j = 16 * (NHh * hh + tl) + cc;
-    double v = 0.0;
-    if (i < T && j < T) v = (c * c) * (0.5 * (Q[(size_t)i * TP + j] + Q[(size_t)j * TP + i]) - 0.5 * (Ki[(size_t)i * TP + j] + Ki[(size_t)j * TP + i]));
-    Mp[idx] = v;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = ty + 8 * r;
+      const int i = 32 * bi + y, j = 32 * bj + tx;
+      double v = 0.0;
+      if (i < T && j < T)
+        v = (c * c) * (0.5 * (Q[(size_t)i * TP + j] + tq[tx][y]) - 0.5 * (Ki[(size_t)i * TP + j] + tk[tx][y]));
+      int jp = j;
+      if (a.interleave) {
+        const int hh = j / (16 * NHh), tl = (j / 16) % NHh, cc = j % 16;
+        const int loc = (tl < 2 * (NHh / 2)) ? 32 * (tl / 2) + 2 * cc + (tl & 1) : 16 * (NHh - 1) + cc;
+        jp = 16 * NHh * hh + loc;
+      }
+      Mp[(size_t)i * TP + jp] = v;
+    }
   }
-  if (blockIdx.y != 0) return;
+  // a' = c Kinv mean and the row sums of |Kinv| (rows dealt to the gridDim.y blocks of the cluster)
   const double* mu = a.mean + (size_t)k * T;
   __shared__ double red[256];
   double rmax = 0.0;
-  for (int i = tid; i < TP; i += 256) {
+  for (int i = blockIdx.y * 256 + tid; i < TP; i += gridDim.y * 256) {
     double s = 0.0, rs = 0.0;
-    if (i < T)
+    if (i < T) {
+#pragma unroll 8
       for (int j = 0; j < T; ++j) {
         const double kij = Ki[(size_t)j * TP + i];   // K~^{-1} = Z^T Z is symmetric: read column-wise, coalesced
         s = fma(kij, mu[j], s);
         rs += fabs(kij);
       }
+    }
     a.ap[(size_t)k * TP + i] = c * s;
     rmax = fmax(rmax, rs);
   }
@@ -1346,7 +1360,9 @@ __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
     if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
     __syncthreads();
   }
-  if (tid == 0) a.scal[8 * k + 6] = red[0];   // ||K~^{-1}||_inf >= ||K~^{-1}||_2
+  // ||K~^{-1}||_inf >= ||K~^{-1}||_2: maximum over the blocks (non-negative doubles order like their bit patterns;
+  // k_prep_build zeroes the slot)
+  if (tid == 0) atomicMax(reinterpret_cast<unsigned long long*>(a.scal + 8 * k + 6), (unsigned long long)__double_as_longlong(red[0]));
 }
 
 // -------------------------------------------------------------------------------------- a2 + a5
