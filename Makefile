@@ -1,19 +1,27 @@
-# Build libhdpgpc_hip.so (gfx950) and the CPU oracle helpers.  `python -c "import __graft_entry__ as g; g.build()"` runs this.
+# Build libhdpgpc_hip.so (gfx950).  `python -c "import __graft_entry__ as g; g.build()"` runs this.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
-SRC    = hdpgpc_amd/csrc/hgp_kernels.hip
-HDR    = hdpgpc_amd/csrc/tile_f64.hpp include/hdpgpc_hip.h
+CSRC   = hdpgpc_amd/csrc
+SRCS   = $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs_acc.hip
+HDR    = $(CSRC)/tile_f64.hpp $(CSRC)/hgp_internal.hpp include/hdpgpc_hip.h
+OBJDIR = build/obj
+OBJS   = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 LIB    = hdpgpc_amd/lib/libhdpgpc_hip.so
+FLAGS  = -O3 --offload-arch=$(ARCH) -mllvm -pragma-unroll-threshold=1048576 -fPIC -Wno-unused-result
 
 all: $(LIB)
 
-$(LIB): $(SRC) $(HDR)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDR)
+	mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
 	mkdir -p hdpgpc_amd/lib
-	$(HIPCC) -O3 --offload-arch=$(ARCH) -mllvm -pragma-unroll-threshold=1048576 -shared -fPIC -Wno-unused-result -o $@ $(SRC)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 # diagnostic build with in-kernel cycle stamps (tools/stamps.py); never used by the product path
-stamps: $(SRC) $(HDR)
-	$(HIPCC) -O3 --offload-arch=$(ARCH) -mllvm -pragma-unroll-threshold=1048576 -DHGP_STAMPS -shared -fPIC -Wno-unused-result -o hdpgpc_amd/lib/libhdpgpc_hip_stamps.so $(SRC)
+stamps: $(SRCS) $(HDR)
+	$(HIPCC) $(FLAGS) -DHGP_STAMPS -shared -o hdpgpc_amd/lib/libhdpgpc_hip_stamps.so $(SRCS)
 
 clean:
-	rm -f $(LIB)
+	rm -rf $(LIB) $(OBJDIR)

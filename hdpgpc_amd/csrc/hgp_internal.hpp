@@ -1,0 +1,69 @@
+// Host-side declarations shared by the translation units of libhdpgpc_hip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "../../include/hdpgpc_hip.h"
+
+constexpr int WAVES = 4;  // waves per workgroup of the one-wave-per-item kernels: one per SIMD of a CU
+
+static inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : 1000 + (int)e;
+}
+
+static inline int nb_for(int n) {  // tile count, rounded to the instantiated sizes {2,4,6,8}
+  int nb = (n + 15) / 16;
+  nb = (nb + 1) & ~1;
+  return nb < 2 ? 2 : nb;
+}
+
+static inline bool env_on(const char* name) {
+  const char* v = getenv(name);
+  return v && v[0] && v[0] != '0';
+}
+
+// Entries of E = exp(-h) and of K** / c with h > PAIRS_CUT (value < 1e-36) are dropped block-wise: a 16x16 block
+// whose entries are ALL below that is neither built nor multiplied.  What is dropped changes a covariance entry by
+// less than 2 T max|M'| 1e-36, far below one ulp; with the reference's length-scale 1.2 on a unit-spaced grid only
+// the blocks |Kt - J| <= 1 survive, which removes ~60 % of the MFMA work at T = 128.  The decision is taken from the
+// data (any grid), never from an assumed band structure.
+constexpr double PAIRS_CUT = 82.9;
+
+// number of workgroups (and S scratch areas) of the solve-based pairs kernel (hgp_pairs_acc.hip)
+static inline int acc_grid_for(int nb) { return nb > 8 ? 256 : 512; }
+
+struct hgp_pairs_plan {
+  int T, K, TP, NB;
+  std::vector<double> theta;           // host copy [K,3]
+  std::vector<int32_t> perm;           // clusters sorted by length-scale
+  std::vector<int> grp_beg, grp_end;   // ranges of `perm` sharing one length-scale
+  std::vector<double> grp_ell;
+  // device carve-up
+  double *d_theta, *d_scal, *d_A, *d_S, *d_Z, *d_Kinv, *d_P, *d_Q, *d_Mp, *d_ap, *d_xb;
+  int32_t* d_perm;
+  bool coop = false;   // one workgroup per pair (k_pairs_coop): always for T > 128
+  // cooperative kernel: overflow areas for the E blocks of dense grids
+  double* d_escr = nullptr;
+  int32_t* d_eflags = nullptr;
+  int nscr = 0;
+  long escr_stride = 0;
+  // solve-based evaluation (hgp_pairs_acc.hip) for the clusters whose explicit operator M' would lose digits:
+  double acc_tol = 1e-9;        // cluster k takes the solve-based kernel when eps (c ||K~^-1||_inf)^2 > acc_tol
+  double* d_Lop = nullptr;      // [K][NB(NB-1)/2 strictly lower tiles][64][4]: A operand of L[K,K']
+  double* d_LTop = nullptr;     // same tiles: A operand of L[K,K']^T
+  double* d_Dop = nullptr;      // [K][4 kinds][NB][64][4]: diagonal-block operands (W4, masked L_KK; plain and transposed)
+  double* d_Sop = nullptr;      // [K][NB][NB][64][4]: A operand of tile (K,K') of 0.5 (Sigma + Sigma^T)
+  double* d_mu = nullptr;       // [K][TP] prior means on the basis grid (zero padded)
+  int32_t* d_acc_list = nullptr;   // [1 + K]: number of flagged clusters, then their ids
+  double* d_sscr = nullptr;     // [acc_grid][NB*NB][64][4]: per-workgroup storage of S = K~^{-1} K*
+};
+
+// hgp_pairs_acc.hip
+int hgp_internal_acc_prep(hgp_pairs_plan* p, const double* mean, hipStream_t st);
+int hgp_internal_pairs_acc(const hgp_pairs_plan* p, const double* x, const double* y, int N, int Ts, const double* first_noise,
+                           const int32_t* sel, double* out_quad, double* out_logdet, int32_t* out_info, hipStream_t st);
+size_t hgp_internal_acc_bytes(int TP, int K, size_t* sizes /*[6]*/);

@@ -10,24 +10,12 @@
 #include <vector>
 
 #include "../../include/hdpgpc_hip.h"
+#include "hgp_internal.hpp"
 #include "tile_f64.hpp"
 
 using namespace hgp;
 
 namespace {
-
-constexpr int WAVES = 4;  // waves per workgroup: one per SIMD of a CU
-
-inline int launch_status() {
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : 1000 + (int)e;
-}
-
-inline int nb_for(int n) {  // tile count, rounded to the instantiated sizes {2,4,6,8}
-  int nb = (n + 15) / 16;
-  nb = (nb + 1) & ~1;
-  return nb < 2 ? 2 : nb;
-}
 
 // ------------------------------------------------------------------------------------------ a1
 __global__ void k_gram_rbf(const double* __restrict__ x, int nx, const double* __restrict__ y, int ny, double c,
@@ -1394,12 +1382,7 @@ struct PairsArgs {
   long escr_stride;
 };
 
-// Entries of E = exp(-h) and of K** / c with h > PAIRS_CUT (value < 1e-36) are dropped block-wise: a 16x16 block
-// whose entries are ALL below that is neither built nor multiplied.  What is dropped changes a covariance entry by
-// less than 2 T max|M'| 1e-36, far below one ulp; with the reference's length-scale 1.2 on a unit-spaced grid only
-// the blocks |Kt - J| <= 1 survive, which removes ~60 % of the MFMA work at T = 128.  The decision is taken from the
-// data (any grid), never from an assumed band structure.
-constexpr double PAIRS_CUT = 82.9;
+// PAIRS_CUT (block-wise cut-off of E and K**): hgp_internal.hpp
 #ifdef HGP_STAMPS
 static unsigned long long* g_stamp_dev = nullptr;   // host-side handle of the diagnostic counters (8 x u64)
 #endif
@@ -1483,6 +1466,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     if (a.sel && a.sel[n] != kc) continue;
     HGP_T0();
     const double* sc = a.scal + 8 * kc;
+    if (sc[7] != 0.0) continue;   // ill-conditioned K~: this cluster is scored by the solve-based kernel (hgp_pairs_acc.hip)
     const double cc = sc[0], noise = sc[2];
     const bool iso = sc[3] != 0.0;
     const size_t oidx = a.sel ? (size_t)n : (size_t)n * a.K + kc;
@@ -1769,6 +1753,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
     }
     kc = a.perm[a.kbeg + kk];
   }
+  if (a.scal[8 * kc + 7] != 0.0) return;   // ill-conditioned K~: scored by the solve-based kernel (hgp_pairs_acc.hip)
 
   HGP_STAMP_DECL
   HGP_T0();
@@ -2119,6 +2104,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
     }
     kc = a.perm[a.kbeg + kk];
   }
+  if (a.scal[8 * kc + 7] != 0.0) return;   // ill-conditioned K~: scored by the solve-based kernel (hgp_pairs_acc.hip)
 
   HGP_STAMP_DECL
   HGP_T0();
@@ -2461,33 +2447,12 @@ int launch_pairs(const PairsArgs& a, hipStream_t st) {
 // =============================================================================================
 // C-ABI
 // =============================================================================================
-struct hgp_pairs_plan {
-  int T, K, TP, NB;
-  std::vector<double> theta;           // host copy [K,3]
-  std::vector<int32_t> perm;           // clusters sorted by length-scale
-  std::vector<int> grp_beg, grp_end;   // ranges of `perm` sharing one length-scale
-  std::vector<double> grp_ell;
-  // device carve-up
-  double *d_theta, *d_scal, *d_A, *d_S, *d_Z, *d_Kinv, *d_P, *d_Q, *d_Mp, *d_ap, *d_xb;
-  int32_t* d_perm;
-  bool coop = false;   // one workgroup per pair (k_pairs_coop): always for T > 128
-  // cooperative kernel: overflow areas for the E blocks of dense grids
-  double* d_escr = nullptr;
-  int32_t* d_eflags = nullptr;
-  int nscr = 0;
-  long escr_stride = 0;
-};
-
 static int tp_for(int n) {   // padded size: wave kernels {32,64,96,128}, cooperative kernels {192,256}
   if (n <= HGP_MAX_T_WAVE) return 16 * nb_for(n);
   return n <= 192 ? 192 : 256;
 }
 // Diagnostic switches: HGP_PAIRS_COOP=1 (read when a plan is created) runs the cooperative kernels for T <= 128 too;
 // HGP_PAIRS_COOP4=1 (read per call) selects the 4-wave cooperative kernel instead of the NB/2-wave one.
-static bool env_on(const char* name) {
-  const char* v = getenv(name);
-  return v && v[0] && v[0] != '0';
-}
 static int tp_plan(int n) {
   if (n <= HGP_MAX_T_WAVE && env_on("HGP_PAIRS_COOP")) return 64 * ((n + 63) / 64);
   return tp_for(n);
@@ -2522,6 +2487,12 @@ static size_t plan_bytes(int T, int Ts_max, int K, size_t* offs /*[24]*/) {
     const size_t nscr = over ? (nb >= 12 ? 512 : 1024) : 0;
     tmp[22] = take(nscr * over * 256 * sizeof(double));
     tmp[23] = take((nscr + 1) * sizeof(int32_t));
+  }
+  {   // solve-based kernel (hgp_pairs_acc.hip): packed operands of L, Sigma; mean copy; per-workgroup S areas; flag list
+    size_t sz[6];
+    hgp_internal_acc_bytes((int)TP, K, sz);
+    for (int i = 0; i < 6; ++i) tmp[12 + i] = take(sz[i]);
+    tmp[18] = take((size_t)(K + 1) * sizeof(int32_t));
   }
   if (offs) memcpy(offs, tmp, sizeof(tmp));
   return o;
@@ -2636,6 +2607,13 @@ int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const
   p->d_ap = (double*)(base + offs[9]);
   p->d_perm = (int32_t*)(base + offs[10]);
   p->d_xb = (double*)(base + offs[11]);
+  p->d_Lop = (double*)(base + offs[12]);
+  p->d_LTop = (double*)(base + offs[13]);
+  p->d_Dop = (double*)(base + offs[14]);
+  p->d_Sop = (double*)(base + offs[15]);
+  p->d_mu = (double*)(base + offs[16]);
+  p->d_sscr = (double*)(base + offs[17]);
+  p->d_acc_list = (int32_t*)(base + offs[18]);
   if (p->coop) {
     const size_t cap = (p->NB >= 12) ? 48 : (p->NB == 8 ? 24 : 16);
     const size_t over = (size_t)p->NB * p->NB > cap ? (size_t)p->NB * p->NB - cap : 0;
@@ -2689,7 +2667,17 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   launch_gemm(g3, K, st);
   PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap, p->coop ? 0 : 1};
   hipLaunchKernelGGL(k_prep_final, dim3(K, 8), dim3(256), 0, st, fin);
-  return launch_status();
+  // overflow-area flags: a launch that was killed mid-flight must not leave areas marked busy for the next one
+  if (p->d_eflags && p->nscr > 0 && hipMemsetAsync(p->d_eflags, 0, (p->nscr + 1) * sizeof(int32_t), st) != hipSuccess) return launch_status();
+  // clusters whose explicit operator would lose digits take the solve-based kernel: flags + packed operands of L, Sigma
+  int rc = hgp_internal_acc_prep(p, mean, st);
+  return rc ? rc : launch_status();
+}
+
+int hgp_pairs_plan_set_accuracy(hgp_pairs_plan* p, double tol) {
+  if (!p || tol != tol) return -1;
+  p->acc_tol = tol;
+  return 0;
 }
 
 int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double* y, int N, int Ts,
@@ -2725,6 +2713,7 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
       default: rc = launch_pairs<8>(a, st); break;
     }
   }
+  if (rc == 0) rc = hgp_internal_pairs_acc(p, x, y, N, Ts, first_noise, sel, out_quad, out_logdet, out_info, st);
   return rc;
 }
 

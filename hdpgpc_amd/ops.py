@@ -159,9 +159,13 @@ def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=
 
 
 class PairsPlan:
-    """a2+a5 for an N x K batch: per-cluster operators (plan) + the per-pair kernel."""
+    """a2+a5 for an N x K batch: per-cluster operators (plan) + the per-pair kernels.
 
-    def __init__(self, T, Ts_max, theta, device="cuda"):
+    acc_tol selects, per cluster and on the device, between the two evaluations of cov_f (hgp_pairs_plan_set_accuracy):
+    clusters whose accuracy_bound() exceeds it (ill-conditioned K~, e.g. the drivers' ini_lengthscale = 3.0) are scored
+    by the solve-based kernel (the reference's operation order, GPI.py:489-501); 0 = all clusters, < 0 = none."""
+
+    def __init__(self, T, Ts_max, theta, device="cuda", acc_tol=1e-9):
         theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(-1, 3))
         self.T, self.Ts_max, self.K = int(T), int(Ts_max), theta.shape[0]
         self.theta = theta
@@ -174,6 +178,13 @@ class PairsPlan:
                                                   theta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                                   _ptr(self._buf), nbytes), "pairs_plan_create")
         self.info = torch.zeros(self.K, dtype=torch.int32, device=device)
+        self.set_accuracy(acc_tol)
+
+    def set_accuracy(self, tol):
+        """Threshold on accuracy_bound() above which a cluster takes the solve-based kernel (next update())."""
+        self.acc_tol = float(tol)
+        _ffi.check(_ffi.lib.hgp_pairs_plan_set_accuracy(self._h, self.acc_tol), "pairs_plan_set_accuracy")
+        return self
 
     def update(self, x_basis, mean, Sigma):
         """x_basis [T]; mean [K,T] (= C f on the basis grid); Sigma [K,T,T]."""
@@ -186,16 +197,21 @@ class PairsPlan:
         return self
 
     def scalars(self):
-        """[K,8] device view: c, ell, noise, iso flag, mean diag Sigma, jitter, ||K~^-1||_inf, 0."""
+        """[K,8] device view: c, ell, noise, iso flag, mean diag Sigma, jitter, ||K~^-1||_inf, solve-based flag."""
         base = _ffi.lib.hgp_pairs_plan_scalars(self._h)
         off = base - self._buf.data_ptr()
         return self._buf[off:off + self.K * 64].view(torch.float64).view(self.K, 8)
 
     def accuracy_bound(self):
         """eps * (c ||K~^-1||_inf)^2 per cluster: growth of the rounding error of the explicit-operator evaluation
-        relative to the reference's triangular solves (host sync).  ~1e-10 at the reference's length-scale."""
+        relative to the reference's triangular solves (host sync).  ~1e-10 at the reference's length-scale.  The plan
+        compares it with acc_tol on the device; nothing on the scoring path needs this host copy."""
         s = self.scalars().cpu().numpy()
         return np.finfo(np.float64).eps * (s[:, 0] * s[:, 6]) ** 2
+
+    def solve_based(self):
+        """Boolean [K] (host sync): clusters the last update() routed to the solve-based kernel."""
+        return self.scalars()[:, 7].cpu().numpy() != 0.0
 
     def loglik(self, x, y, first_noise=None, want_logdet=True, want_info=True, sel=None):
         """x, y [N,Ts] -> (quad [N,K], logdet [N,K] or None, info [N,K] or None).

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HGP_ABI_VERSION 2   /* 2: + hgp_gemm_add_batched_f64, hgp_add_diag_mean_f64, hgp_lds_chain_*_f64, hgp_rts_chain_f64 */
+#define HGP_ABI_VERSION 3   /* 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path) */
 /* largest T (basis length) and T* (segment length) served by the register-resident wave kernels */
 #define HGP_MAX_T_WAVE 128
 /* largest T served at all: 128 < T <= 256 runs on cooperative kernels (one workgroup of 4-8 waves per matrix / pair) */
@@ -110,6 +110,12 @@ int hgp_pairs_plan_update(hgp_pairs_plan* plan, const double* x_basis, const dou
  * reference's triangular solves grows like eps * (c * kinv)^2 (about 1e-10 for the reference's length-scale
  * 1.2 on a unit-spaced grid, where parity is 1e-11; quickly worse for smoother kernels) - callers check it. */
 const double* hgp_pairs_plan_scalars(const hgp_pairs_plan* plan);
+/* Which clusters take the solve-based evaluation (the reference's operation order, GPI.py:489-501: S = cholesky_solve(K*, L)
+ * by blocked substitution per pair, cov_f = K** + S^T (Sigma S - K*)) instead of the explicit operator M:
+ *   tol > 0 : the clusters with eps * (c * kinv)^2 > tol   (default 1e-9; decided on the device inside hgp_pairs_plan_update)
+ *   tol == 0: every cluster;   tol < 0: none (explicit operator everywhere).
+ * Takes effect at the next hgp_pairs_plan_update. */
+int hgp_pairs_plan_set_accuracy(hgp_pairs_plan* plan, double tol);
 /* x[N,Ts], y[N,Ts]: segment grids and values.  first_noise[N,K] (may be NULL): additive diagonal of the
  * `first` branch (GPI_model.py:271-273).  Outputs [N,K]: out_quad = d^T cov^{-1} d, out_logdet (may be NULL),
  * out_info (may be NULL).  cov carries the reference's regularisation: +1e-6 I (GPI.py:501, dense Sigma only),

@@ -179,6 +179,56 @@ def gen_pred_dist():
     np.savez_compressed(os.path.join(OUT, "pred_dist.npz"), **out)
 
 
+
+# ------------------------------------------- a2 + a5 at the drivers' ini_lengthscale (ill-conditioned K~)
+def gen_pairs_ill():
+    """Per-pair path (pred_dist + log_sq_error score) where K~ is ill-conditioned: the length-scale every driver
+    constructs its kernels with (ini_lengthscale = 3.0, hdpgpc/tests/test_offline.py:51, test_online.py:53) and 2.5, on
+    irregular grids at T = 45 / 90 / 128 (plus one case with T* != T).  Scores come from the reference's own
+    GPI_model.log_sq_error(mean=, C=, Sigma=, i=0) -> observe(params) -> pred_dist (GPI_model.py:250-286,657-662)."""
+    rng = np.random.default_rng(21)
+    out = {}
+    i = 0
+    for (T, Ts) in [(45, 45), (90, 90), (128, 128), (90, 64)]:
+        for ell in (2.5, 3.0):
+            xb = np.arange(float(T))[:, None]
+            K, N = 3, 5
+            thetas, means, Sigs = [], [], []
+            for k in range(K):
+                c, noise = 300.0 * (1 + 0.1 * k), 0.9 * (1 + 0.5 * k)
+                thetas.append((c, ell, noise))
+                v = rng.normal(size=T)
+                Sigs.append(rng.uniform(0.5, 5.0) * (np.eye(T) + 0.1 * np.outer(v, v)))
+                means.append((100 + 50 * k) * np.exp(-0.5 * ((xb[:, 0] - T * (0.3 + 0.2 * k)) / (0.08 * T)) ** 2)
+                             + rng.normal(size=T))
+            if Ts == T:
+                x = xb[None, :, 0] + rng.uniform(-0.3, 0.3, (N, T))
+            else:
+                x = np.linspace(0, T - 1, Ts)[None, :] + rng.uniform(-0.2, 0.2, (N, Ts))
+            z = rng.integers(0, K, N)
+            y = np.stack([np.interp(x[n], xb[:, 0], means[z[n]]) for n in range(N)]) + rng.normal(0, 3.0, (N, Ts))
+            score = np.zeros((N, K))
+            score_first = np.zeros((N, K))
+            eyeT = torch.eye(T)
+            for k in range(K):
+                c, _, noise = thetas[k]
+                gm = GM.GPI_model(make_kernel(c, ell, noise), xb, verbose=False)
+                cond = gm.GPR_dynamic(0.5, 2.0)
+                gm.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
+                for n in range(N):
+                    xt, yt = torch.from_numpy(x[n][:, None]), torch.from_numpy(y[n][:, None])
+                    kw = dict(mean=torch.from_numpy(means[k][:, None]), cov=eyeT, C=eyeT, Sigma=torch.from_numpy(Sigs[k]), i=0)
+                    score[n, k] = float(gm.log_sq_error(xt, yt, **kw))
+                    score_first[n, k] = float(gm.log_sq_error(xt, yt, first=True, **kw))
+            out[f"c{i}_xb"], out[f"c{i}_x"], out[f"c{i}_y"] = xb[:, 0], x, y
+            out[f"c{i}_theta"], out[f"c{i}_mean"], out[f"c{i}_Sigma"] = np.array(thetas), np.stack(means), np.stack(Sigs)
+            out[f"c{i}_score"], out[f"c{i}_score_first"] = score, score_first
+            out[f"c{i}_ini_noise"] = np.array(1e-2 * 2.0)          # first: 1e-2 mean diag Sigma[0], Sigma[0] = 2.0 I
+            i += 1
+    out["n_cases"] = np.array(i)
+    np.savez_compressed(os.path.join(OUT, "pairs_ill.npz"), **out)
+    print(f"pairs_ill: {i} cases")
+
 # --------------------------------------------------------- a5-a9 on a real LDS state
 def load_beats(rec, n, stride=1, lead=0):
     d = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:n, ::stride, [lead]]
@@ -364,13 +414,15 @@ def gen_offline(tag, rec, n, stride):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gram", "score", "pred", "state", "lml", "warp", "offline"]
+    which = sys.argv[1:] or ["gram", "score", "pred", "ill", "state", "lml", "warp", "offline"]
     if "gram" in which:
         gen_gram()
     if "score" in which:
         gen_score_shared()
     if "pred" in which:
         gen_pred_dist()
+    if "ill" in which:
+        gen_pairs_ill()
     if "state" in which:
         gen_state("t30", "100", 14, 3, [2, 5, 6, 9, 12], 11)
         gen_state("t45", "102", 24, 2, [0, 1, 2, 3, 4, 7, 8, 11, 15, 16, 20], 12)

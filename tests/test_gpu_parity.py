@@ -189,18 +189,27 @@ def test_pairs_against_reference_irregular_grids(tag):
 
 
 def test_pairs_accuracy_bound_tracks_conditioning():
-    """The explicit per-cluster operator loses digits when K~ is ill-conditioned; the plan reports a bound."""
+    """The explicit per-cluster operator loses digits when K~ is ill-conditioned; the plan reports a bound and routes
+    the clusters above its tolerance to the solve-based kernel (tests/test_gpu_pairs_acc.py)."""
     T, N, K = 48, 4, 2
     b = orc.synthetic_batch(N, K, T, seed=5)
     b["theta"][1, 1] = 2.5                                # smooth kernel: cond(K~) ~ 1e7
-    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    _, q_ref, _ = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
+    # explicit operator everywhere (acc_tol < 0): the error of the ill-conditioned cluster follows the indicator
+    plan = ops.PairsPlan(T, T, b["theta"], acc_tol=-1.0).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
     bound = plan.accuracy_bound()
     assert bound[0] < 1e-8 and bound[1] > 1e-6
+    assert not plan.solve_based().any()
     quad, _, _ = plan.loglik(dev(b["x"]), dev(b["y"]))
-    _, q_ref, _ = orc.loglik_pairs(b["x"], b["y"], b["xb"], b["theta"], b["mean"], b["Sigma"])
     err = np.abs(quad.cpu().numpy() - q_ref) / np.abs(q_ref)
     assert err[:, 0].max() < RT_PAIR
     assert err[:, 1].max() < 10 * bound[1]                # the indicator is of the right order
+    # default tolerance: the ill-conditioned cluster (only) is scored by the solve-based kernel, at full accuracy
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    assert list(plan.solve_based()) == [False, True]
+    quad, _, info = plan.loglik(dev(b["x"]), dev(b["y"]))
+    assert int(info.abs().max()) == 0
+    assert rel_err(quad.cpu().numpy(), q_ref) < RT_PAIR
 
 
 def test_pairs_block_skipping_on_arbitrary_grids():

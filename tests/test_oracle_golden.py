@@ -144,3 +144,16 @@ def test_hmm_messages_8f3():
     assert np.allclose(b, g["bmsg"], rtol=1e-12, atol=0)
     fin = np.isfinite(g["log_respPair"])
     assert np.array_equal(np.isfinite(c), fin) and np.allclose(c[fin], g["log_respPair"][fin], rtol=1e-12, atol=0)
+
+
+def test_pairs_ill_conditioned_lengthscales():
+    """a2 + a5 at the drivers' ini_lengthscale = 3.0 (and 2.5) on irregular grids, T = 45 / 90 / 128 and T* != T: the
+    reference's own GPI_model.log_sq_error outputs (tests/golden/pairs_ill.npz)."""
+    g = golden("pairs_ill.npz")
+    for i in range(int(g["n_cases"])):
+        x, y, xb, th = g[f"c{i}_x"], g[f"c{i}_y"], g[f"c{i}_xb"], g[f"c{i}_theta"]
+        score, _, _ = orc.loglik_pairs(x, y, xb, th, g[f"c{i}_mean"], g[f"c{i}_Sigma"])
+        assert rel_err(score, g[f"c{i}_score"]) < RTOL
+        fn = np.full(score.shape, float(g[f"c{i}_ini_noise"]))
+        score_f, _, _ = orc.loglik_pairs(x, y, xb, th, g[f"c{i}_mean"], g[f"c{i}_Sigma"], first_noise=fn)
+        assert rel_err(score_f, g[f"c{i}_score_first"]) < RTOL
