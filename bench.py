@@ -7,8 +7,10 @@ A step = one pass of the hot path over one batch of synthetic segments:
     (hgp_loglik_pairs_f64), inputs resident in HBM
   + for N_gpus > 1: one RCCL all-gather of the [N, K] score rows back to every rank (the sampler's view).
 Workload at 1 GPU = BASELINE.json configs[1]: 2 048 segments x 8 clusters, T = 128, fp64, irregular
-segment grids (the general path of pred_dist).  Segments shard across ranks with the per-GPU batch fixed
-(weak scaling); cluster state is replicated.
+segment grids (the general path of pred_dist).  At N > 1 GPUs the workload is configs[3], as north_star states it:
+32 768 segments x 16 clusters, T = 256, rows [r N/G, (r+1) N/G) on rank r (STRONG scaling: the batch is fixed,
+4 096 rows per GPU at 8 GPUs), cluster state broadcast once from rank 0, scores returned by one all-gather
+(hdpgpc_amd.batch.emission_scores - the function the tests exercise is the function timed here).
 
 Prints ONE JSON line (rank 0).  Run: python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with
 python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -34,29 +36,35 @@ def algorithmic_flops_per_eval(T):
     return T ** 3 / 3.0 + 3.0 * T ** 2
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(budget_s=20.0):
     """The oracle (NumPy/SciPy restatement of the reference's per-pair path) on the host cores, bounded sample: one
     single-threaded worker process per core of this process's share (at most 16 - the one-GPU box's share), each
-    scoring its own slice of the SAME workload for `budget_s` seconds.  The rate is the sum of the workers' rates."""
+    scoring its own slice of the SAME workload (at most `budget_s` seconds each).  The rate is the sum of the workers'
+    rates.  Runs BEFORE the first GPU call of this process (the workers are separate processes either way)."""
     import subprocess
     cores = max(1, min(16, len(os.sched_getaffinity(0))))
     per = N_SEG // cores
+    t_wall = time.perf_counter()
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", str(w * per), str((w + 1) * per), str(N_SEG),
                                str(K_CL), str(T_LEN), "20260703", str(budget_s)], cwd=ROOT, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for w in range(cores)]
-    done, rate = 0, 0.0
+    done, rate, cpu_s, slow = 0, 0.0, 0.0, 0.0
     for p in procs:
         try:
             out, _ = p.communicate(timeout=budget_s + 120)
             r = json.loads(out.strip().splitlines()[-1])
             done += r["done"]
             rate += r["done"] / r["dt"]
+            cpu_s += r["dt"]
+            slow = max(slow, r["dt"])
         except Exception:                 # a worker that failed or overran contributes nothing
             p.kill()
+    t_wall = time.perf_counter() - t_wall
     return {"value": rate, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"{done} evals of the same workload (T={T_LEN}, {K_CL} clusters) in {budget_s:.0f} s on {cores} worker "
-                      f"processes, one BLAS thread each; NumPy/SciPy oracle"}
+            "sample": f"{done} evals of the same workload (T={T_LEN}, {K_CL} clusters): {cpu_s:.1f} CPU-seconds of scoring on "
+                      f"{cores} worker processes, one BLAS thread each (slowest worker {slow:.2f} s, {t_wall:.1f} s wall with "
+                      f"start-up); NumPy/SciPy oracle"}
 
 
 def secondary_shared_grid(dev, ops, S=16384, T=90, reps=10):
@@ -87,10 +95,10 @@ def secondary_shared_grid(dev, ops, S=16384, T=90, reps=10):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
 
 
-def secondary_large_T(dev, ops, synth, N=1024, K=16, T=256, reps=3):
-    """BASELINE configs[3] shape on ONE GPU (a quarter of its 4 096 segments per GPU): 16 clusters, T = 256, irregular
-    grids - the cooperative pairs kernel (one workgroup per pair).  Same accounting as the headline: algorithmic
-    FLOPs T^3/3 + 3T^2 per eval against the fp64 MFMA peak."""
+def secondary_large_T(dev, ops, synth, N=4096, K=16, T=256, reps=3):
+    """BASELINE configs[3]'s per-GPU shard on ONE GPU (4 096 of its 32 768 segments = the 8-GPU share): 16 clusters,
+    T = 256, irregular grids - the cooperative pairs kernel (one workgroup per pair).  Same accounting as the headline:
+    algorithmic FLOPs T^3/3 + 3T^2 per eval against the fp64 MFMA peak."""
     b = synth.synthetic_batch(N, K, T, seed=20260703)
     d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
     plan = ops.PairsPlan(T, T, b["theta"], device=dev)
@@ -111,7 +119,7 @@ def secondary_large_T(dev, ops, synth, N=1024, K=16, T=256, reps=3):
     assert int(info.abs().max()) == 0 and bool(torch.isfinite(quad).all())
     ms = e0.elapsed_time(e1) / reps
     tf = N * K * algorithmic_flops_per_eval(T) / (ms * 1e-3) / 1e12
-    return {"workload": f"configs[3] shape on one GPU: {N} segments x {K} clusters, T={T}, irregular grids (k_pairs_cooph<16>)",
+    return {"workload": f"configs[3] per-GPU shard on one GPU: {N} segments x {K} clusters, T={T}, irregular grids (k_pairs_cooph<16>)",
             "value": N * K / dt, "unit": "evals/s", "ms_per_step": dt * 1e3, "kernel_ms": ms,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T)}}
@@ -157,6 +165,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only (used for the PMC passes)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on a one-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--segments", type=int, default=0, help="override the batch size (rehearsals only; 0 = the named config)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,6 +174,9 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # the CPU baseline (rank 0, N = 1 only) runs before this process touches the GPU
+    cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
+
     import torch.distributed as dist
     if args.single_device:
         local = 0
@@ -178,31 +190,33 @@ def main():
             dist.init_process_group(args.backend)
 
     import synthetic_workload as synth        # workload generator: plain NumPy, independent of oracle/
-    from hdpgpc_amd import ops
+    from hdpgpc_amd import batch, ops
 
-    batch = synth.synthetic_batch(N_SEG, K_CL, T_LEN, seed=20260703 + rank)
-    cl = synth.synthetic_batch(1, K_CL, T_LEN, seed=20260703)          # cluster state is replicated: same on every rank
-    for k in ("xb", "theta", "mean", "Sigma"):
-        batch[k] = cl[k]
+    if world == 1:   # configs[1]
+        n_seg, k_cl, t_len, kern = N_SEG, K_CL, T_LEN, "k_pairs<8>"
+        name = "BASELINE configs[1]: synthetic 2048 segments x 8 clusters, T=128, fp64, irregular segment grids"
+    else:            # configs[3], strong scaling: the whole batch is fixed, rank r scores rows [r N/G, (r+1) N/G)
+        n_seg, k_cl, t_len, kern = 32768, 16, 256, "k_pairs_cooph<16>"
+        name = "BASELINE configs[3]: synthetic 32768 segments x 16 clusters, T=256, fp64, irregular segment grids"
+    if args.segments:
+        n_seg = args.segments
+    b = synth.synthetic_batch(n_seg, k_cl, t_len, seed=20260703)      # segments: replicated on every rank (inputs)
     d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
-    xb, mean, Sig, x, y = d(batch["xb"]), d(batch["mean"]), d(batch["Sigma"]), d(batch["x"]), d(batch["y"])
-    plan = ops.PairsPlan(T_LEN, T_LEN, batch["theta"], device=dev)
-    q_all = torch.empty((world * N_SEG, K_CL), dtype=torch.float64, device=dev) if world > 1 else None
+    x, y = d(b["x"]), d(b["y"])
+    # cluster state: owned by rank 0, replicated with ONE broadcast; the other ranks pass placeholders
+    if rank == 0:
+        theta, xb, mean, Sig = batch.broadcast_cluster_state(b["theta"], b["xb"], b["mean"], b["Sigma"], dev)
+    else:
+        theta, xb, mean, Sig = batch.broadcast_cluster_state(np.zeros_like(b["theta"]), np.zeros_like(b["xb"]),
+                                                             np.zeros_like(b["mean"]), np.zeros_like(b["Sigma"]), dev)
+    plan = ops.PairsPlan(t_len, t_len, theta, device=dev)
+    lo, hi = batch.shard_bounds(n_seg, world, rank)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(i=None):
         plan.update(xb, mean, Sig)
-        if i is not None:
-            ev0[i].record()
-        quad, _, info = plan.loglik(x, y, want_logdet=False)
-        if i is not None:
-            ev1[i].record()
-        score = -0.5 * quad - 0.5 * T_LEN * ops.LOG2PI
-        if world > 1:
-            dist.all_gather_into_tensor(q_all, score)
-            return q_all, info
-        return score, info
+        return batch.emission_scores(plan, x, y, events=None if i is None else (ev0[i], ev1[i]), want_info=True)
 
     for _ in range(args.warmup):
         step()
@@ -222,39 +236,39 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    assert tuple(out.shape) == (n_seg, k_cl)
     assert int(info.abs().max()) == 0 and bool(torch.isfinite(out).all())
 
     if rank == 0:
-        evals = world * N_SEG * K_CL * args.steps
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-        flops = N_SEG * K_CL * algorithmic_flops_per_eval(T_LEN)
+        evals = n_seg * k_cl * args.steps
+        kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)]))
+        flops = (hi - lo) * k_cl * algorithmic_flops_per_eval(t_len)          # per launch on this rank
         achieved = flops / (kern_ms * 1e-3) / 1e12
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pairs_traffic.json")
-        if os.path.exists(tf):
+        if world == 1 and os.path.exists(tf):
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         res = {
             "metric": "GP log-lik evals/sec (NxK batch, T-point segments)",
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic 2048 segments x 8 clusters per GPU, T=128, fp64, "
-                                   "irregular segment grids (per-pair Gram + Cholesky + score)",
-                       "segments_per_gpu": N_SEG, "clusters": K_CL, "T": T_LEN,
-                       "sharding": f"segments x{world}, 1 RCCL all-gather of scores" if world > 1 else "single GPU"},
+            "config": {"workload": name + " (per-pair Gram + Cholesky + score)",
+                       "segments": n_seg, "segments_per_gpu": hi - lo, "clusters": k_cl, "T": t_len,
+                       "sharding": (f"rows [r N/{world}, (r+1) N/{world}) per rank, cluster state broadcast from rank 0, "
+                                    f"1 RCCL all-gather of the score rows") if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "k_pairs<8>", "kernel_ms": kern_ms,
-                         "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T_LEN),
-                         # what the kernel actually issues (band-skipped): 1548 v_mfma_f64_16x16x4 of 2048 FLOP per pair
-                         "executed_mfma_tflops": N_SEG * K_CL * 1548 * 2048 / (kern_ms * 1e-3) / 1e12},
+                         "kernel": kern, "kernel_ms": kern_ms, "pairs_per_launch": (hi - lo) * k_cl,
+                         "algorithmic_flops_per_eval": algorithmic_flops_per_eval(t_len)},
         }
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_shared_grid(dev, ops)
             res["secondary_large_T"] = secondary_large_T(dev, ops, synth)
             res["secondary_rank1"] = secondary_rank1(dev, ops)
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

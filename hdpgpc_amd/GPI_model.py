@@ -106,7 +106,6 @@ class GPI_model:
         self.noise_bounds = (1e-10, 1e10)
         self._stk = {}
         self._pending = []
-        self._sym_cache = {}
 
     # ------------------------------------------------------------------ state (a12)
     def cond_to_torch(self, x):
@@ -139,12 +138,22 @@ class GPI_model:
         return self
 
     def _S(self, name):
-        """Stacked [steps, ...] device tensor of one of the per-step lists (cached until the list grows)."""
+        """Stacked [steps, ...] device tensor of one of the per-step lists (cached until the list changes; every method
+        that rewrites an entry in place resets ``_stk``)."""
         lst = getattr(self, name)
         key = self._stk.get(name)
         if key is None or key[0] != len(lst) or key[1] is not lst[-1]:
-            self._stk[name] = (len(lst), lst[-1], torch.stack(lst).contiguous())
+            self._stk[name] = [len(lst), lst[-1], torch.stack(lst).contiguous(), None]
         return self._stk[name][2]
+
+    def _S_symmetric(self, name):
+        """Is every matrix of the stack equal to its transpose bit for bit?  One device check per stack, stored WITH the
+        stack (it dies with it)."""
+        self._S(name)
+        ent = self._stk[name]
+        if ent[3] is None:
+            ent[3] = bool(torch.equal(ent[2], ent[2].transpose(1, 2)))
+        return ent[3]
 
     # ------------------------------------------------------------------ a7: which state does step t read?
     def _select(self, t):
@@ -266,14 +275,15 @@ class GPI_model:
         return ops.gemm_batched(Z[0], Z[0], transA=True)
 
     def _check_pending(self):
+        """One host sync for all the LAPACK infos collected since the last check; raises like torch.linalg.cholesky."""
         if self._pending:
-            infos = torch.cat([i for _, i in self._pending])
+            pending, self._pending = self._pending, []
+            infos = torch.cat([i.reshape(-1) for _, i in pending])
             if bool(infos.any()):
-                bad = int(torch.nonzero(infos)[0, 0])
-                what = self._pending[bad][0]
-                self._pending = []
+                flat = int(torch.nonzero(infos)[0, 0])
+                sizes = np.cumsum([i.numel() for _, i in pending])
+                what = pending[int(np.searchsorted(sizes, flat, side="right"))][0]      # flat index -> its entry
                 raise torch.linalg.LinAlgError(f"{what}: the input is not positive-definite")
-            self._pending = []
 
     def _posterior(self, mean_prior, cov_prior, y, A, Gamma, C, Sigma, first_step, h=1.0):
         """GPI.posterior (GPI.py:72-151) on the shared grid (x_warped == x_basis, K_cov = I)."""
@@ -343,11 +353,15 @@ class GPI_model:
             self.f_star_sm[-2] = m0 + mm(J, m1 - mm(A, m0))
             self.cov_f_sm[-2] = c0 + mm(mm(J, c1 - P), J, transB=True)
             self.f_star_sm[-1], self.cov_f_sm[-1] = m1, c1
+            self._stk = {}
 
     def bayesian_new_params(self, h, model_type="dynamic", full_data=False, q=None, force=False, snr=1.0):
         """GPI_model.py:966-1115, one-step estimation (full_data=False), dynamic model, shared grid."""
-        if full_data or h != 1.0:
-            raise NotImplementedError("bayesian_new_params: only the one-step update with h = 1 is built")
+        if h != 1.0:          # the reference's whole body sits under `if h == 1.0:` (GPI_model.py:972): a soft member is skipped
+            return
+        if full_data:
+            raise NotImplementedError("bayesian_new_params: only the one-step update (full_data=False) is built")
+        self._stk = {}
         if 1 < self.N < self.estimation_limit or force:
             infos = []
             new_int = self.internal_params.posterior(1, self.f_star_sm[-1], self.f_star_sm[-2], defer=infos)
@@ -422,7 +436,7 @@ class GPI_model:
         ch["y1s"] = torch.zeros((2, T, 1), dtype=f64, device=dev)            # (f_post, y) of the MNIW updates
         ch["y2s"] = torch.zeros((2, T, 1), dtype=f64, device=dev)            # (f_sm_prev, f_post)
         ch["I0"] = torch.stack((eye, torch.zeros_like(eye))).contiguous()    # addends of the batched (I - K C, -K Sigma)
-        ch["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        ch["bad"] = torch.zeros(2, dtype=torch.int32, device=dev)          # [MNIW updates skipped, first step whose filter failed]
         ch["sync"] = torch.zeros(1, dtype=torch.int32, device=dev)           # inter-block counter of hgp_lds_chain_finish_f64
         return ch
 
@@ -459,7 +473,7 @@ class GPI_model:
         mm(CPk, C, transB=True, add=S, out=X5[2])
         ops.add_diag_mean(Rs, scales, 1e-2, out=X5[3:5])
         Z4, i4 = ops.chol_inverse(X5[1:5])
-        self._pending.append(("backwards_pair / posterior", i4[:2]))
+        # (i4 is rewritten by every graph replay: hgp_lds_chain_finish_f64 latches a failure of i4[:2] in ch["bad"][1])
         inv4 = mm(Z4, Z4, transA=True)
         i1, scale_inv = i4[2:], inv4[2:]
         # Kalman update (GPI.py:140-151, Joseph form).  P C^T is the transpose of the C P already formed for S (P is a
@@ -483,7 +497,7 @@ class GPI_model:
         part = mm(mm(S_, Zs, transB=True), Zs)
         e = y1s - y2s
         ops.lds_chain_finish(part, mm(e, e, transB=True), S__, i1, i2, ch["W"], n0, ch["Nf"], ch["bad"], ch["A"], ch["G"],
-                             ch["C"], ch["S"], pos, self.annealing, ch["sync"])
+                             ch["C"], ch["S"], pos, self.annealing, ch["sync"], info0=i4)
 
     def _chain_commit(self, ch, members, x_trains, y_trains):
         L = int(ch["pos"][0]) + 1
@@ -502,30 +516,32 @@ class GPI_model:
         self._stk = {}
 
     def _run_graphed(self, fn, n_iter):
-        """Capture fn() once on a side stream and replay it n_iter times (falls back to eager calls if capture fails)."""
+        """Run fn() n_iter times: once eagerly (warm-up, counts as the first iteration), then captured ONCE as a hipGraph and
+        replayed.  A failed capture or replay raises: silently re-running eagerly would both hide a 30x slow-down and, after
+        a partial replay, apply steps twice."""
         if n_iter <= 0:
             return
         self._check_pending()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()                                        # warm-up iteration (counts as the first one)
+        torch.cuda.current_stream().wait_stream(side)
+        n_iter -= 1
+        if n_iter == 0:
+            return
+        graph = torch.cuda.CUDAGraph()
+        keep = self._pending
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                fn()                                        # warm-up iteration (counts as the first one)
-            torch.cuda.current_stream().wait_stream(side)
-            n_iter -= 1
-            if n_iter == 0:
-                return
-            graph = torch.cuda.CUDAGraph()
-            keep = self._pending
             with torch.cuda.graph(graph):
                 fn()
-            self._pending = keep + self._pending            # info tensors written by every replay
-            for _ in range(n_iter):
-                graph.replay()
-            self._graph_keepalive = graph
-        except RuntimeError:
-            for _ in range(n_iter):
-                fn()
+        except RuntimeError as e:
+            raise RuntimeError(f"hipGraph capture of the LDS step failed: {e}") from e
+        self._pending = keep + self._pending            # info tensors written by every replay
+        for _ in range(n_iter):
+            graph.replay()
+        self.graph_replays = getattr(self, "graph_replays", 0) + n_iter
+        self._graph_keepalive = graph
 
     def _backwards_graphed(self):
         """GPI_model.backwards (full RTS) with the step captured once: index t runs down on the device."""
@@ -604,7 +620,10 @@ class GPI_model:
             ch["y_row0"] = int(ch["pos"][0])
             self._run_graphed(lambda: self._chain_step(ch), len(rest))
             self._chain_commit(ch, rest, x_trains, y_trains)
-            if int(ch["bad"][0]) != 0 and self.verbose:
+            bad = ch["bad"].tolist()
+            if bad[1] != 0:      # torch.linalg.solve / inv of the reference would have raised at that member
+                raise torch.linalg.LinAlgError(f"posterior / backwards_pair: the input is not positive-definite (LDS step {bad[1]})")
+            if bad[0] != 0 and self.verbose:
                 print("Alg error matrix ill conditioned.")     # GPI_model.py:1069
             self._backwards_graphed()
         else:
@@ -724,10 +743,7 @@ class GPI_model:
                 gs = np.nonzero(single)[0]
                 segs = torch.as_tensor(rep[gs], device=self.device)
                 Sst = self._S("Sigma")
-                sym = self._sym_cache.get(id(Sst))
-                if sym is None:      # one device check per stacked tensor: exactly symmetric stacks take the half-traffic path
-                    sym = bool(torch.equal(Sst, Sst.transpose(1, 2)))
-                    self._sym_cache = {id(Sst): sym}
+                sym = self._S_symmetric("Sigma")      # exactly symmetric stacks take the half-traffic path
                 q1, _, info1 = ops.score_each(Y[segs].contiguous(), means.contiguous(), Sst, g_ci[gs].astype(np.int32),
                                               inv[gs].astype(np.int32), adds[gs], symmetric=sym)
                 ops.raise_on_info(info1, "compute_sq_err_all")

@@ -32,7 +32,7 @@ def _load():
         "hgp_add_diag_mean_f64": (i32, [vp, vp, i32, i32, f64, vp, vp]),
         "hgp_gemm_add_batched_f64": (i32, [i32, i32, i32, i32, i32, f64, vp, i32, i64, vp, i32, i64, f64, vp, i32, i64, vp, i32, i64, i32, vp]),
         "hgp_lds_chain_gather_f64": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, vp, vp]),
-        "hgp_lds_chain_finish_f64": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+        "hgp_lds_chain_finish_f64": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
         "hgp_score_groups_f64": (i32, [vp, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, f64, vp, vp, vp, vp]),
         "hgp_score_each_f64": (i32, [vp, i32, vp, i64, vp, i64, i32, vp, vp, vp, i32, f64, i32, vp, vp, vp, vp]),
         "hgp_pairs_plan_device_bytes": (sz, [i32, i32, i32]),

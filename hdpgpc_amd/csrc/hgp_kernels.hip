@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -480,6 +481,7 @@ struct GemmArgs {
   const double* D = nullptr;   // optional addend (instead of C): C = alpha op(A) op(B) + beta D
   int ldd = 0;
   long sD = 0;
+  int boff = 0;                // first batch item of this launch (gridDim.y is capped at 65535: larger batches go in chunks)
 };
 
 // TRIP = k-steps whose operand loads are issued before the first MFMA of a trip.  TRIP = 24 covers Kd <= 96 in ONE
@@ -492,7 +494,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   const int tile = blockIdx.x * WAVES + wave;
   if (tile >= ntm * ntn) return;
   const int ti = tile / ntn, tj = tile % ntn;
-  const int b1 = blockIdx.y / a.nb2, b2 = blockIdx.y % a.nb2;
+  const int by = (int)blockIdx.y + a.boff;
+  const int b1 = by / a.nb2, b2 = by % a.nb2;
   const double* A = a.A + (size_t)b1 * a.sA + (size_t)b2 * a.sA2;
   const double* B = a.B + (size_t)b1 * a.sB + (size_t)b2 * a.sB2;
   double* C = a.C + (size_t)b1 * a.sC + (size_t)b2 * a.sC2;
@@ -526,14 +529,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   }
 }
 
-int launch_gemm(const GemmArgs& a, int batch, hipStream_t st) {
-  const int nt = ((a.M + 15) / 16) * ((a.N + 15) / 16);
-  if (a.Kd <= 96 && a.Kd > 32)
-    hipLaunchKernelGGL(k_gemm<24>, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
-  else if (a.Kd <= 128 && a.Kd > 96)
-    hipLaunchKernelGGL(k_gemm<32>, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
-  else
-    hipLaunchKernelGGL(k_gemm<8>, dim3((nt + WAVES - 1) / WAVES, batch), dim3(64 * WAVES), 0, st, a);
+int launch_gemm(const GemmArgs& a0, int batch, hipStream_t st) {
+  const int nt = ((a0.M + 15) / 16) * ((a0.N + 15) / 16);
+  for (int b0 = 0; b0 < batch; b0 += 65535) {   // gridDim.y <= 65535
+    GemmArgs a = a0;
+    a.boff = b0;
+    const int nb = std::min(65535, batch - b0);
+    if (a.Kd <= 96 && a.Kd > 32)
+      hipLaunchKernelGGL(k_gemm<24>, dim3((nt + WAVES - 1) / WAVES, nb), dim3(64 * WAVES), 0, st, a);
+    else if (a.Kd <= 128 && a.Kd > 96)
+      hipLaunchKernelGGL(k_gemm<32>, dim3((nt + WAVES - 1) / WAVES, nb), dim3(64 * WAVES), 0, st, a);
+    else
+      hipLaunchKernelGGL(k_gemm<8>, dim3((nt + WAVES - 1) / WAVES, nb), dim3(64 * WAVES), 0, st, a);
+  }
   return launch_status();
 }
 
@@ -556,9 +564,10 @@ __global__ __launch_bounds__(256) void k_dot_batched(const double* __restrict__ 
 
 // C[b] = A[b] - B[b]  (elementwise, n per item)
 __global__ void k_sub_batched(const double* __restrict__ A, const double* __restrict__ B, long sA, long sB, long n,
-                              double* __restrict__ C) {
+                              double* __restrict__ C, int b) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (size_t)n) C[(size_t)blockIdx.y * n + i] = A[(size_t)blockIdx.y * sA + i] - B[(size_t)blockIdx.y * sB + i];
+  if (i >= (size_t)n) return;
+  for (int m = blockIdx.y; m < b; m += gridDim.y) C[(size_t)m * n + i] = A[(size_t)m * sA + i] - B[(size_t)m * sB + i];
 }
 
 // r[b] = f_cur[b] - A[b] f_prev[b]   (a8 residual), one workgroup per item
@@ -923,6 +932,7 @@ struct ChainFinishArgs {
   const double* Snew;     // [2,T,T]  S__ (the new right covariance)
   const int32_t* info1;   // [2]
   const int32_t* info2;   // [2]
+  const int32_t* info0;   // [2] or NULL: status of the Kalman / pair-smoother factorisations of this step
   double* W;              // [3,2,T,T] means, R, scales (in/out)
   double* n0;             // device scalars (in/out)
   double* Nf;
@@ -973,6 +983,9 @@ __global__ __launch_bounds__(256) void k_chain_finish(ChainFinishArgs a) {
     a.n0[0] = n0n;
     a.Nf[0] = Nf;
     a.bad_count[0] += bad ? 1 : 0;
+    // bad_count[1]: 1-based index of the first step whose Kalman / smoother factorisation failed (0 = none) - the info
+    // tensors themselves are overwritten by every graph replay
+    if (a.info0 && a.bad_count[1] == 0 && (a.info0[0] | a.info0[1]) != 0) a.bad_count[1] = (int32_t)nxt;
     a.pos[0] = nxt;
     a.sync[0] = 0;
   }
@@ -2774,7 +2787,7 @@ int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_me
   if (hipMemcpyAsync(Sc, Sigma, sizeof(double) * b * tt, hipMemcpyDeviceToDevice, st) != hipSuccess) return launch_status();
   int rc = hgp_potrf_batched_f64(Sc, T, b, 0.0, 1e-8, Z, nullptr, info, stream);   // chol(0.5(S+S^T) + 1e-8 I), GPI_model.py:1353
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sub_batched, dim3((unsigned)((tt + 255) / 256), b), dim3(256), 0, st, M, m_mean, tt, prior_stride, tt, D);
+  hipLaunchKernelGGL(k_sub_batched, dim3((unsigned)((tt + 255) / 256), std::min(b, 65535)), dim3(256), 0, st, M, m_mean, tt, prior_stride, tt, D, b);
   GemmArgs g1{Z, D, Y, T, T, T, T, T, T, tt, tt, tt, 1.0, 0.0, 0, 0};              // Y = L^{-1} D
   if ((rc = launch_gemm(g1, b, st))) return rc;
   if (m_r_cov) {                                                                     // sum (D R) o Sigma^{-1} D = sum (Y R) o Y
@@ -2852,22 +2865,30 @@ int hgp_rts_chain_f64(const double* J, const double* P, const double* AM, double
   if (n < 2) return 0;
   RtsArgs a{J, P, AM, M, Cv, n, T};
   const size_t lds = sizeof(double) * (2 * 96 * 100 + 96);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rts_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  {   // the attribute is per device: set it once for each device this process launches on
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dv = 0;
+    if (hipGetDevice(&dv) != hipSuccess) return launch_status();
+    std::lock_guard<std::mutex> lk(mu);
+    if (dv < 0 || dv >= 64 || !done[dv]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rts_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return 1000 + (int)e;
+      if (dv >= 0 && dv < 64) done[dv] = true;
+    }
   }
   hipLaunchKernelGGL(k_rts_chain, dim3(1), dim3(64 * RTS_WAVES), lds, (hipStream_t)stream, a);
   return launch_status();
 }
 
 int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const double* Snew, const int32_t* info1,
-                             const int32_t* info2, double* W, double* n0, double* Nf, int32_t* bad_count, double* stA,
-                             double* stG, double* stC, double* stS, int64_t* pos, int annealing, int32_t* sync, void* stream) {
+                             const int32_t* info2, const int32_t* info0, double* W, double* n0, double* Nf, int32_t* bad_count,
+                             double* stA, double* stG, double* stC, double* stS, int64_t* pos, int annealing, int32_t* sync,
+                             void* stream) {
   if (!part || !ee || !Snew || !info1 || !info2 || !W || !n0 || !Nf || !bad_count || !stA || !stG || !stC || !stS || !pos ||
       !sync || T <= 0)
     return -1;
-  ChainFinishArgs a{T, part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing, sync};
+  ChainFinishArgs a{T, part, ee, Snew, info1, info2, info0, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing, sync};
   const long n2 = 2L * T * T;
   hipLaunchKernelGGL(k_chain_finish, dim3((unsigned)std::min<long>(64, (n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();

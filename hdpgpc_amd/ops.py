@@ -371,10 +371,10 @@ def lds_chain_gather(stA, stG, stC, stS, stPsm, stP, stF, stFsm, pos, out, Y=Non
     return out
 
 
-def lds_chain_finish(part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing, sync):
+def lds_chain_finish(part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, pos, annealing, sync, info0=None):
     """8f-1 glue: element-wise tail of the two MNIW updates + append of A, Gamma, C, Sigma + counters (see the header)."""
     T = stA.shape[1]
-    _ffi.check(_ffi.lib.hgp_lds_chain_finish_f64(T, _ptr(part), _ptr(ee), _ptr(Snew), _ptr(info1), _ptr(info2), _ptr(W), _ptr(n0),
+    _ffi.check(_ffi.lib.hgp_lds_chain_finish_f64(T, _ptr(part), _ptr(ee), _ptr(Snew), _ptr(info1), _ptr(info2), _ptr(info0), _ptr(W), _ptr(n0),
                                                  _ptr(Nf), _ptr(bad_count), _ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(pos),
                                                  int(bool(annealing)), _ptr(sync), _stream()), "lds_chain_finish")
 

@@ -173,7 +173,9 @@ int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const do
  *     n0' = n0 + 1 (unless bad);  Nf' = Nf + 1;  scl = n0' / (n0' - 2);  ann = annealing ? 1 / Nf'^2 : 0
  *     A[pos+1] = means'[0]; C[pos+1] = means'[1]; Gamma[pos+1] = scales'[0] scl + Gamma[0] ann; Sigma likewise
  *                                                        (bayesian_new_params, GPI_model.py:1076-1106)
- *     W = (means', R', scales') [3,2,T,T];  n0, Nf, bad_count, pos updated in place (pos += 1).
+ *     W = (means', R', scales') [3,2,T,T];  n0, Nf, bad_count[2], pos updated in place (pos += 1).
+ *     bad_count[0] counts the steps that kept their previous distributions; info0[2] (may be NULL) is the status of the
+ *     step's Kalman / pair-smoother factorisations: the first step (row index) where one failed is latched in bad_count[1].
  *     sync: one int32 the caller zero-initialises once (inter-block counter, left at zero). */
 int hgp_lds_chain_gather_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stPsm,
                              const double* stP, const double* stF, const double* stFsm, const int64_t* pos, int T,
@@ -196,8 +198,9 @@ int hgp_gemm_add_batched_f64(int transA, int transB, int M, int N, int Kd, doubl
                              const double* B, int ldb, long strideB, double beta, const double* D, int ldd, long strideD,
                              double* C, int ldc, long strideC, int batch, void* stream);
 int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const double* Snew, const int32_t* info1,
-                             const int32_t* info2, double* W, double* n0, double* Nf, int32_t* bad_count, double* stA,
-                             double* stG, double* stC, double* stS, int64_t* pos, int annealing, int32_t* sync, void* stream);
+                             const int32_t* info2, const int32_t* info0, double* W, double* n0, double* Nf, int32_t* bad_count,
+                             double* stA, double* stG, double* stC, double* stS, int64_t* pos, int annealing, int32_t* sync,
+                             void* stream);
 
 /* a10 helper - || G^{-1} y ||^2 for the lower triangle G of a [T, ld] matrix.  IterativeGaussianProcess.
  * log_marginal_likelihood as written passes K itself as the "factor" to cho_solve (GPI.py:1043); this reproduces

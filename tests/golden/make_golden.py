@@ -265,7 +265,20 @@ def dump_state(gm, prefix, out):
     out[prefix + "n0"] = np.array(float(gm.internal_params.n0))
 
 
-def gen_state(tag, rec, n, stride, members, seed):
+def gen_state(tag, rec, n, stride, members, seed, theta=None):
+    """theta overrides the injected kernel hyper-parameters (e.g. the drivers' ini_lengthscale = 3.0 in place of the
+    1.2 that GPI.py:711 forces after a valid fit: the state of a model whose kernel was never (validly) fitted)."""
+    global THETA_INJECT
+    keep = THETA_INJECT
+    if theta is not None:
+        THETA_INJECT = theta
+    try:
+        _gen_state(tag, rec, n, stride, members, seed)
+    finally:
+        THETA_INJECT = keep
+
+
+def _gen_state(tag, rec, n, stride, members, seed):
     rng = np.random.default_rng(seed)
     data = load_beats(rec, n, stride)
     gm, x_trains, y_trains, q, q_lat = build_model(data, members)
@@ -427,6 +440,8 @@ if __name__ == "__main__":
         gen_state("t30", "100", 14, 3, [2, 5, 6, 9, 12], 11)
         gen_state("t45", "102", 24, 2, [0, 1, 2, 3, 4, 7, 8, 11, 15, 16, 20], 12)
         gen_state("t90", "100", 8, 1, [0, 1, 3, 6], 13)
+    if "state_l3" in which or "state" in which:
+        gen_state("t45l3", "102", 24, 2, [0, 1, 2, 3, 4, 7, 8, 11, 15, 16, 20], 12, theta=(341.0, 3.0, 4.66))
     if "lml" in which:
         gen_lml()
     if "warp" in which:

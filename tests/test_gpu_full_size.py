@@ -18,10 +18,10 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
 
 
-@pytest.mark.parametrize("N,K,T,n_spot", [(2048, 8, 128, 16), (512, 16, 256, 4)])
+@pytest.mark.parametrize("N,K,T,n_spot", [(2048, 8, 128, 16), (4096, 16, 256, 4)])
 def test_full_size_batch_properties(N, K, T, n_spot):
-    """configs[1] (2 048 x 8, T = 128) and the per-GPU shape of configs[3] (16 clusters, T = 256; 512 of its 4 096
-    segments) on irregular grids."""
+    """configs[1] (2 048 x 8, T = 128) and the per-GPU shard of configs[3] (4 096 segments x 16 clusters, T = 256) on
+    irregular grids."""
     b = orc.synthetic_batch(N, K, T, seed=20260703)
     xb, mean, Sig = dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"])
     x, y = dev(b["x"]), dev(b["y"])

@@ -32,7 +32,7 @@ def model_from(g, prefix="st_"):
     return m
 
 
-@pytest.mark.parametrize("tag", ["t30", "t45", "t90"])
+@pytest.mark.parametrize("tag", ["t30", "t45", "t90", "t45l3"])
 def test_gpi_model_scoring_half(tag):
     g = golden(f"state_{tag}.npz")
     m = model_from(g)
@@ -188,6 +188,48 @@ def test_producer_full_pass_weighted_reproduces_reference_state(tag, members):
     assert float(m.internal_params.n0) == float(g["st_n0"])
     assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-6
     assert rel_err(q_lat.cpu().numpy()[members], g["q_lat"][members]) < 1e-6
+
+
+def test_soft_members_are_skipped_like_the_reference():
+    """A responsibility in (0.99, 1) (e.g. 0.9999 from the variational step) makes a segment 'active' but h != 1: the
+    reference then skips it entirely - include_sample(posterior=False), backwards_pair and bayesian_new_params are no-ops
+    (GPI_model.py:353-375,705-716,972).  The state must equal the hard members' state of the fixture, not crash."""
+    g = golden("state_t45.npz")
+    y = g["y"]
+    n, T = y.shape
+    members = [int(v) for v in g["st_indexes"]]
+    sigma, gamma = float(g["st_Sigma"][0][0, 0]), float(g["st_Gamma"][0][0, 0])
+    xs = np.repeat(g["st_x_basis"][None, :, None], n, axis=0)
+    for use_graphs in (True, False):
+        m = GPI_model(RBFWhiteKernel(300.0, 3.0, sigma * 1e-5), g["st_x_basis"][:, None], annealing=True, bayesian=True, free_deg_MNIV=5)
+        cond = m.GPR_dynamic(gamma, sigma)
+        m.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
+        m.fixed_theta = tuple(float(v) for v in g["st_theta"])
+        resp = np.zeros(n)
+        resp[members] = 1.0
+        resp[[5, 9, 21]] = 0.995                       # soft members between hard ones
+        q, q_lat = m.full_pass_weighted(xs, y[:, :, None], resp, use_graphs=use_graphs)
+        assert m.indexes == members
+        for name in ("f_star", "f_star_sm"):
+            got = torch.stack(getattr(m, name)).cpu().numpy()[:, :, 0]
+            assert np.allclose(got, g["st_" + name], rtol=1e-7, atol=1e-7 * np.abs(g["st_" + name]).max()), name
+        for name in ("A", "Gamma", "C", "Sigma"):
+            got = torch.stack(getattr(m, name)).cpu().numpy()
+            assert np.allclose(got, g["st_" + name], rtol=1e-7, atol=1e-7 * np.abs(g["st_" + name]).max()), name
+        assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-6
+
+
+def test_pending_info_names_the_failing_step():
+    """_check_pending maps the flat index of the first non-zero LAPACK info back to the entry it belongs to and raises
+    torch.linalg.LinAlgError (what callers of the reference catch, GPI_model.py:1068)."""
+    m = GPI_model(RBFWhiteKernel(1.0, 1.0, 0.1), np.arange(8.0)[:, None])
+    z = lambda k: torch.zeros(k, dtype=torch.int32, device="cuda")  # noqa: E731
+    bad = z(3)
+    bad[1] = 4
+    m._pending = [("first", z(2)), ("second", z(5)), ("third", bad), ("fourth", z(1))]
+    with pytest.raises(torch.linalg.LinAlgError, match="third"):
+        m._check_pending()
+    assert m._pending == []
 
 
 def test_replay_offline_trace_from_labels():

@@ -93,7 +93,7 @@ def test_score_shared_cov_a4_golden():
         assert np.allclose(logdet.cpu().numpy(), orc.quad_logdet(Y[0] - mean, cov)[1], rtol=1e-10)
 
 
-@pytest.mark.parametrize("tag", ["t30", "t45", "t90"])
+@pytest.mark.parametrize("tag", ["t30", "t45", "t90", "t45l3"])
 def test_grouped_scoring_a6_state(tag):
     """compute_sq_err_all on the shared grid: groups from the host logic, Sigma_i stack scored on the GPU."""
     g = golden(f"state_{tag}.npz")
@@ -160,7 +160,7 @@ def test_pairs_iso_and_first_and_mixed_lengthscales():
     assert rel_err(logdet.cpu().numpy(), ld_ref) < RT_PAIR
 
 
-@pytest.mark.parametrize("tag", ["t30", "t45", "t90"])
+@pytest.mark.parametrize("tag", ["t30", "t45", "t90", "t45l3"])
 def test_pairs_against_reference_irregular_grids(tag):
     """q_irr of the fixtures = the reference's compute_sq_err_all on irregular grids (per-segment state)."""
     g = golden(f"state_{tag}.npz")

@@ -57,7 +57,7 @@ def test_pred_dist_a2():
         assert np.allclose(covl, g[f"c{i}_cov_lat"], rtol=1e-8, atol=1e-8 * np.abs(g[f"c{i}_cov_lat"]).max())
 
 
-@pytest.mark.parametrize("tag", ["t30", "t45", "t90"])
+@pytest.mark.parametrize("tag", ["t30", "t45", "t90", "t45l3"])
 def test_state_paths_a5_to_a9(tag):
     g = golden(f"state_{tag}.npz")
     st = _state(g)
