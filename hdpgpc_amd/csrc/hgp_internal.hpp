@@ -67,3 +67,9 @@ int hgp_internal_acc_prep(hgp_pairs_plan* p, const double* mean, hipStream_t st)
 int hgp_internal_pairs_acc(const hgp_pairs_plan* p, const double* x, const double* y, int N, int Ts, const double* first_noise,
                            const int32_t* sel, double* out_quad, double* out_logdet, int32_t* out_info, hipStream_t st);
 size_t hgp_internal_acc_bytes(int TP, int K, size_t* sizes /*[6]*/);
+
+// hgp_matlik.hip: fused one-wave-per-item kernels of a8 / a9 (T <= HGP_MAX_T_WAVE)
+int hgp_internal_lat_error_wave(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* covprev,
+                                int T, int b, double* out, int32_t* info, hipStream_t st);
+int hgp_internal_mniw_wave(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov, const double* scale,
+                           long prior_stride, int T, int b, double* out, int32_t* info, hipStream_t st);

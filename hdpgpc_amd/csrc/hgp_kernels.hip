@@ -2743,10 +2743,12 @@ size_t hgp_matrix_lik_ws_bytes(int T, int b) { return (size_t)b * ((size_t)4 * T
 
 int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* covprev,
                       int T, int b, double* out, int32_t* info, void* ws, size_t ws_bytes, void* stream) {
-  if (!f_cur || !f_prev || !A || !Gamma || !covprev || !out || !ws || T <= 0 || b < 0) return -1;
+  if (!f_cur || !f_prev || !A || !Gamma || !covprev || !out || T <= 0 || b < 0) return -1;
   if (b == 0) return 0;
-  if (T > HGP_MAX_T_WAVE) return -2;
-  if (ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;
+  if (T > HGP_MAX_T_COOP) return -2;
+  if (T <= HGP_MAX_T_WAVE)   // fused: one wavefront per item, nothing goes through the workspace
+    return hgp_internal_lat_error_wave(f_cur, f_prev, A, Gamma, covprev, T, b, out, info, (hipStream_t)stream);
+  if (!ws || ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;   // 128 < T <= 256: composition of the batched kernels
   hipStream_t st = (hipStream_t)stream;
   const long tt = (long)T * T;
   double* Gc = (double*)ws;          // copy of Gamma -> L
@@ -2774,10 +2776,12 @@ int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A
 int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov,
                         const double* scale, long prior_stride, int T, int b, double* out, int32_t* info, void* ws,
                         size_t ws_bytes, void* stream) {
-  if (!M || !Sigma || !m_mean || !scale || !out || !ws || T <= 0 || b < 0) return -1;
+  if (!M || !Sigma || !m_mean || !scale || !out || T <= 0 || b < 0) return -1;
   if (b == 0) return 0;
-  if (T > HGP_MAX_T_WAVE) return -2;
-  if (ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;
+  if (T > HGP_MAX_T_COOP) return -2;
+  if (T <= HGP_MAX_T_WAVE)   // fused: one wavefront per item, nothing goes through the workspace
+    return hgp_internal_mniw_wave(M, Sigma, m_mean, m_r_cov, scale, prior_stride, T, b, out, info, (hipStream_t)stream);
+  if (!ws || ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;   // 128 < T <= 256: composition of the batched kernels
   hipStream_t st = (hipStream_t)stream;
   const long tt = (long)T * T;
   double* Sc = (double*)ws;

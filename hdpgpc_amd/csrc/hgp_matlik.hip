@@ -1,0 +1,268 @@
+// a8 (GPI_model.log_lat_error, GPI_model.py:288-323) and a9 (matrix_normal_inv_wishart.log_likelihood_MNIW,
+// GPI_model.py:1346-1362) as ONE kernel each, one wavefront per item, T <= 128: the matrix-valued terms are traces of the
+// form  tr(X^T G^{-1} Y) = sum (L^{-1} X) o (L^{-1} Y)  with G = L L^T, and a forward solve acts on the columns of its
+// right-hand side independently - so the wave factors G once in registers (tile_f64.hpp), then walks the 16-column panels:
+// builds the two right-hand-side panels (GEMMs on the matrix core straight from global memory), forward-solves both with
+// the stored factor and accumulates their element-wise product.  No intermediate matrix ever goes to memory (the first
+// version was a 5-kernel composition through 4 T^2 doubles of workspace per item: 1.2 M evals/s at T = 90).
+//   a8:  r = f_cur - A f_prev;  out = -0.5 (|L^{-1} r|^2 + sum (L^{-1} (A P)) o (L^{-1} A)),         G = _chol_spd(Gamma)
+//   a9:  D = M - m_mean;        out = -0.5 sum (L^{-1} (D R)) o (L^{-1} D) - 0.5 sum (L^{-1} S) o (L^{-1} I),  G = Sigma + 1e-8 I
+// Algorithmic bytes per item: 3 T^2 + 2 T doubles (a8), 2-4 T^2 (a9, the prior shared by all items).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "hgp_internal.hpp"
+#include "tile_f64.hpp"
+
+using namespace hgp;
+
+namespace {
+
+// tile (I, J) of a row-major [n, n] matrix (ld = n) in accumulator layout, zero outside; optionally minus a second matrix
+__device__ __forceinline__ d4 load_acc_tile(const double* __restrict__ A, const double* __restrict__ B, int n, int I, int J, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 16 * I + g + 4 * r, j = 16 * J + c;
+    double x = 0.0;
+    if (i < n && j < n) {
+      x = A[(size_t)i * n + j];
+      if (B) x -= B[(size_t)i * n + j];
+    }
+    v[r] = x;
+  }
+  return v;
+}
+
+// the same tile as the A operand of a product (lane (g, c) holds X[16 I + c][16 K + 4 s + g] in element s)
+__device__ __forceinline__ d4 load_aop_tile(const double* __restrict__ A, const double* __restrict__ B, int n, int I, int K, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  d4 v;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int i = 16 * I + c, k = 16 * K + 4 * s + g;
+    double x = 0.0;
+    if (i < n && k < n) {
+      x = A[(size_t)i * n + k];
+      if (B) x -= B[(size_t)i * n + k];
+    }
+    v[s] = x;
+  }
+  return v;
+}
+
+template <int NB>
+__device__ __forceinline__ double tiles_dot(const d4 (&X)[NB], const d4 (&Y)[NB], int K0 = 0) {
+  double s = 0.0;
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+    if (K < K0) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s = fma(X[K][r], Y[K][r], s);
+  }
+  return s;
+}
+
+// R[:, J] = (X - X2) Pm[:, J]  (X2, Pm2 optional subtrahends; Pm tile rows beyond n are zero)
+template <int NB>
+__device__ __forceinline__ void panel_gemm(d4 (&R)[NB], const double* __restrict__ X, const double* __restrict__ X2,
+                                           const double* __restrict__ Pm, int n, int J, int lane_in) {
+#pragma unroll
+  for (int K = 0; K < NB; ++K) R[K] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma nounroll
+  for (int Kk = 0; Kk < NB; ++Kk) {
+    const int lane = launder(lane_in);
+    if (16 * Kk >= n) break;
+    const d4 pb = load_acc_tile(Pm, nullptr, n, Kk, J, lane);      // B operand: rows 16Kk + 4s + g, column 16J + c
+#pragma unroll
+    for (int K = 0; K < NB; ++K) {
+      const d4 xa = load_aop_tile(X, X2, n, K, Kk, lane);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) R[K] = mfma(xa[s], pb[s], R[K]);
+    }
+  }
+}
+
+struct LatArgs {
+  const double* f_cur;
+  const double* f_prev;
+  const double* A;
+  const double* Gamma;
+  const double* P;
+  int T, b;
+  double* out;
+  int32_t* info;
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_wave_lat(LatArgs a) {
+  __shared__ __attribute__((aligned(16))) double scr_all[WAVES * DIAG_SCR];
+  __shared__ __attribute__((aligned(16))) double w_all[WAVES * NB * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int it = blockIdx.x * WAVES + wave;
+  if (it >= a.b) return;
+  double* scr = scr_all + wave * DIAG_SCR;
+  double* Wl = w_all + wave * NB * 256;
+  const int T = a.T;
+  const size_t tt = (size_t)T * T;
+  const double* A = a.A + it * tt;
+  const double* P = a.P + it * tt;
+  d4 U[NB * (NB + 1) / 2];
+  d4 R1[NB], R2[NB];
+  load_sym_upper<NB>(U, a.Gamma + it * tt, T, T, lane, scr);
+  {
+    const double dm = diag_abs_mean<NB>(U, T, lane);
+    add_diag<NB>(U, 1e-8 * fmax(dm, F64_EPS), T, lane);           // _chol_spd, GPI_model.py:83-87
+  }
+  PivotAcc pa;
+  pa.init();
+  wave_factor<NB, 0, (NB >= 8)>(U, R1, scr, Wl, nullptr, lane, pa, nullptr, 0, T);
+  double acc = 0.0;
+  // vector panel: column 0 = r = f_cur - A f_prev (the product rides the matrix core with f_prev as a one-column operand)
+  {
+    const double* fc = a.f_cur + (size_t)it * T;
+    const double* fp = a.f_prev + (size_t)it * T;
+#pragma unroll
+    for (int K = 0; K < NB; ++K)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * K + g + 4 * r;
+        R1[K][r] = (c == 0 && i < T) ? fc[i] : 0.0;
+      }
+#pragma nounroll
+    for (int Kk = 0; Kk < NB; ++Kk) {
+      const int ln = launder(lane);
+      if (16 * Kk >= T) break;
+      d4 fb;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 16 * Kk + 4 * s + (ln >> 4);
+        fb[s] = ((ln & 15) == 0 && k < T) ? fp[k] : 0.0;
+      }
+#pragma unroll
+      for (int K = 0; K < NB; ++K) {
+        const d4 xa = load_aop_tile(A, nullptr, T, K, Kk, ln);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) R1[K] = mfma_sub(xa[s], fb[s], R1[K]);
+      }
+    }
+    wave_fwd_solve<NB>(U, Wl, R1, lane);
+    acc += tiles_dot<NB>(R1, R1);                                  // |L^{-1} r|^2 (the other columns are zero)
+  }
+#pragma nounroll
+  for (int J = 0; J < NB; ++J) {
+    const int ln = launder(lane);
+    if (16 * J >= T) break;
+    panel_gemm<NB>(R1, A, nullptr, P, T, J, ln);                   // (A P)[:, J]
+#pragma unroll
+    for (int K = 0; K < NB; ++K) R2[K] = load_acc_tile(A, nullptr, T, K, J, ln);
+    wave_fwd_solve<NB>(U, Wl, R1, ln);
+    wave_fwd_solve<NB>(U, Wl, R2, ln);
+    acc += tiles_dot<NB>(R1, R2);                                  // tr(A^T Gamma^{-1} A P), columns of panel J
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    a.out[it] = -0.5 * acc;
+    if (a.info) a.info[it] = pa.info;
+  }
+}
+
+struct MniwArgs {
+  const double* M;
+  const double* Sigma;
+  const double* m_mean;
+  const double* R;        // may be NULL = identity
+  const double* S;
+  long prior_stride;
+  int T, b;
+  double* out;
+  int32_t* info;
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_wave_mniw(MniwArgs a) {
+  __shared__ __attribute__((aligned(16))) double scr_all[WAVES * DIAG_SCR];
+  __shared__ __attribute__((aligned(16))) double w_all[WAVES * NB * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int it = blockIdx.x * WAVES + wave;
+  if (it >= a.b) return;
+  double* scr = scr_all + wave * DIAG_SCR;
+  double* Wl = w_all + wave * NB * 256;
+  const int T = a.T;
+  const size_t tt = (size_t)T * T;
+  const double* M = a.M + it * tt;
+  const double* mm = a.m_mean + (size_t)it * a.prior_stride;
+  const double* Rm = a.R ? a.R + (size_t)it * a.prior_stride : nullptr;
+  const double* Sm = a.S + (size_t)it * a.prior_stride;
+  d4 U[NB * (NB + 1) / 2];
+  d4 R1[NB], R2[NB];
+  load_sym_upper<NB>(U, a.Sigma + it * tt, T, T, lane, scr);
+  add_diag<NB>(U, 1e-8, T, lane);                                  // chol(0.5 (S + S^T) + 1e-8 I), GPI_model.py:1353
+  PivotAcc pa;
+  pa.init();
+  wave_factor<NB, 0, (NB >= 8)>(U, R1, scr, Wl, nullptr, lane, pa, nullptr, 0, T);
+  double acc = 0.0;
+#pragma nounroll
+  for (int J = 0; J < NB; ++J) {
+    const int ln = launder(lane);
+    if (16 * J >= T) break;
+    // mean term: sum (L^{-1} (D R)) o (L^{-1} D), D = M - m_mean
+#pragma unroll
+    for (int K = 0; K < NB; ++K) R2[K] = load_acc_tile(M, mm, T, K, J, ln);
+    wave_fwd_solve<NB>(U, Wl, R2, ln);
+    if (Rm) {
+      panel_gemm<NB>(R1, M, mm, Rm, T, J, ln);
+      wave_fwd_solve<NB>(U, Wl, R1, ln);
+      acc += tiles_dot<NB>(R1, R2);
+    } else {
+      acc += tiles_dot<NB>(R2, R2);
+    }
+    // scale term: tr(Sigma^{-1} S) = sum (L^{-1} S) o (L^{-1} I); the identity panel is zero above block J
+#pragma unroll
+    for (int K = 0; K < NB; ++K) {
+      R1[K] = load_acc_tile(Sm, nullptr, T, K, J, ln);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R2[K][r] = (K == J && (ln >> 4) + 4 * r == (ln & 15)) ? 1.0 : 0.0;
+    }
+    wave_fwd_solve<NB>(U, Wl, R1, ln);
+    wave_fwd_solve<NB>(U, Wl, R2, ln, J);
+    acc += tiles_dot<NB>(R1, R2, J);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    a.out[it] = -0.5 * acc;
+    if (a.info) a.info[it] = pa.info;
+  }
+}
+
+}  // namespace
+
+int hgp_internal_lat_error_wave(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* covprev,
+                                int T, int b, double* out, int32_t* info, hipStream_t st) {
+  LatArgs a{f_cur, f_prev, A, Gamma, covprev, T, b, out, info};
+  dim3 grid((b + WAVES - 1) / WAVES), blk(64 * WAVES);
+  switch (nb_for(T)) {
+    case 2: hipLaunchKernelGGL(k_wave_lat<2>, grid, blk, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_wave_lat<4>, grid, blk, 0, st, a); break;
+    case 6: hipLaunchKernelGGL(k_wave_lat<6>, grid, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL(k_wave_lat<8>, grid, blk, 0, st, a); break;
+  }
+  return launch_status();
+}
+
+int hgp_internal_mniw_wave(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov, const double* scale,
+                           long prior_stride, int T, int b, double* out, int32_t* info, hipStream_t st) {
+  MniwArgs a{M, Sigma, m_mean, m_r_cov, scale, prior_stride, T, b, out, info};
+  dim3 grid((b + WAVES - 1) / WAVES), blk(64 * WAVES);
+  switch (nb_for(T)) {
+    case 2: hipLaunchKernelGGL(k_wave_mniw<2>, grid, blk, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_wave_mniw<4>, grid, blk, 0, st, a); break;
+    case 6: hipLaunchKernelGGL(k_wave_mniw<6>, grid, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL(k_wave_mniw<8>, grid, blk, 0, st, a); break;
+  }
+  return launch_status();
+}

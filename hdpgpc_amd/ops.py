@@ -149,6 +149,10 @@ def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=
         return a.to(device=dev, dtype=dt).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
 
     sm, sme, sa = up(seg_mat, torch.int32), up(seg_mean, torch.int32), up(seg_add, torch.float64)
+    if T > 128:   # cooperative kernels: one work item (one workgroup) per segment
+        ar = torch.arange(n, dtype=torch.int32, device=dev)
+        return score_groups(Y, mean, Sigma, sm, sa, ar, torch.ones(n, dtype=torch.int32, device=dev), jitter_rel=jitter_rel,
+                            want_logdet=want_logdet, want_info=want_info, item_mean=sme)
     quad = torch.zeros(n, dtype=torch.float64, device=dev)
     logdet = torch.zeros(n, dtype=torch.float64, device=dev) if want_logdet else None
     info = torch.zeros(n, dtype=torch.int32, device=dev) if want_info else None
@@ -316,8 +320,8 @@ def lat_error(f_cur, f_prev, A, Gamma, covprev):
     b, T = f_cur.shape
     out = torch.empty(b, dtype=torch.float64, device=A.device)
     info = torch.zeros(b, dtype=torch.int32, device=A.device)
-    nws = _ffi.lib.hgp_matrix_lik_ws_bytes(T, b)
-    ws = torch.empty(nws, dtype=torch.uint8, device=A.device)
+    nws = _ffi.lib.hgp_matrix_lik_ws_bytes(T, b) if T > 128 else 0     # T <= 128: one fused kernel, no workspace
+    ws = torch.empty(nws, dtype=torch.uint8, device=A.device) if nws else None
     _ffi.check(_ffi.lib.hgp_lat_error_f64(_ptr(f_cur), _ptr(f_prev), _ptr(A), _ptr(Gamma), _ptr(covprev), T, b, _ptr(out),
                                           _ptr(info), _ptr(ws), nws, _stream()), "lat_error")
     return out, info
@@ -333,8 +337,8 @@ def mniw_loglik(M, Sigma, m_mean, m_r_cov, scale):
         m_r_cov = _dev64(m_r_cov, "m_r_cov")
     out = torch.empty(b, dtype=torch.float64, device=M.device)
     info = torch.zeros(b, dtype=torch.int32, device=M.device)
-    nws = _ffi.lib.hgp_matrix_lik_ws_bytes(T, b)
-    ws = torch.empty(nws, dtype=torch.uint8, device=M.device)
+    nws = _ffi.lib.hgp_matrix_lik_ws_bytes(T, b) if T > 128 else 0     # T <= 128: one fused kernel, no workspace
+    ws = torch.empty(nws, dtype=torch.uint8, device=M.device) if nws else None
     _ffi.check(_ffi.lib.hgp_mniw_loglik_f64(_ptr(M), _ptr(Sigma), _ptr(m_mean), _ptr(m_r_cov), _ptr(scale), stride, T, b,
                                             _ptr(out), _ptr(info), _ptr(ws), nws, _stream()), "mniw_loglik")
     return out, info

@@ -132,7 +132,9 @@ int hgp_gemm_batched_f64(int transA, int transB, int M, int N, int Kd, double al
                          const double* B, int ldb, long strideB, double beta, double* C, int ldc, long strideC, int batch,
                          void* stream);
 
-/* workspace (bytes) of the two matrix-valued likelihood terms below for b items of size T */
+/* workspace (bytes) of the two matrix-valued likelihood terms below for b items of size T; only read for 128 < T <= 256
+ * (composition of the batched kernels) - for T <= 128 each term is ONE fused kernel, one wavefront per item, and ws may
+ * be NULL */
 size_t hgp_matrix_lik_ws_bytes(int T, int b);
 
 /* a8 - GPI_model.log_lat_error (GPI_model.py:288-323), batched over b LDS steps:
