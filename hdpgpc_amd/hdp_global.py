@@ -1,0 +1,117 @@
+"""Top level of the HDP-HMM (host side, O(K) work): the stick-breaking weights q(u_k) = Beta(rho_k omega_k, (1 - rho_k) omega_k)
+and the Dirichlet pseudo-counts of the transition rows.
+
+The reference takes this step from bnpy (hdpgpc/hdpgpc/OptimizerRhoOmega.py, "adapted from bnpy"; GPI_HDP.py:360-430,
+2752-2828); it is control plane, not part of the GP-emission hot path, and only enters the drop-in surface through the
+transition / start pseudo-counts that `cluster_new_batch` reads.  What is restated here is the published objective
+(Hughes, Stephenson & Sudderth, "Scalable adaptation of state complexity for nonparametric hidden Markov models", 2015,
+surrogate bound for E[log Dir]), minimised with scipy's L-BFGS-B in the unconstrained variables
+(logit rho, log omega), with the tolerance schedule of the reference's driver of that optimiser.
+"""
+import warnings
+
+import numpy as np
+import scipy.optimize
+from scipy.special import digamma, gammaln, polygamma
+
+EPS = 1e-8
+
+
+def create_initrho(K):
+    """rho whose implied E[beta] is nearly uniform with a small leftover mass (GPI_HDP.py:380-384)."""
+    rem = min(0.1, 1.0 / (K * K))
+    delta = (-1.0 + rem) * np.arange(0.0, K, 1.0)
+    return (1.0 - rem) / (K + delta)
+
+
+def rho2beta(rho, size="K+1"):
+    """E[beta] from the stick fractions (GPI_HDP.py:432-440): K active weights (+ the leftover mass)."""
+    rho = np.asarray(rho, dtype=np.float64)
+    if size == "K":
+        beta = rho.copy()
+        beta[1:] *= np.cumprod(1.0 - rho[:-1])
+        return beta
+    beta = np.append(rho, 1.0)
+    beta[1:] *= np.cumprod(1.0 - rho)
+    return beta
+
+
+def calc_theta_full(trans_count, start_count, M, rho, trans_alpha, start_alpha, kappa):
+    """Dirichlet pseudo-counts of the M x M transition table and the start vector (GPI_HDP.py:400-421): prior mass
+    alpha E[beta] on every column, observed counts (+ sticky kappa) on the leading (M-1) x (M-1) block."""
+    rho = np.asarray(rho, dtype=np.float64)
+    ebeta = rho2beta(rho, "K" if M == rho.shape[0] else "K+1")
+    trans = np.zeros((M, M)) + trans_alpha * ebeta[None, :]
+    tc = np.asarray(trans_count, dtype=np.float64)
+    trans[:M - 1, :M - 1] += tc[:M - 1, :M - 1] + kappa * np.eye(M - 1)
+    start = start_alpha * ebeta
+    start[:M - 1] += np.asarray(start_count, dtype=np.float64)[:M - 1]
+    return trans, start
+
+
+def _objective(rhoomega, T_vec, n_doc, gamma, kappa, K):
+    """Negative surrogate ELBO in (rho, omega) and its gradient."""
+    rho, omega = rhoomega[:K], rhoomega[K:]
+    g1, g0 = rho * omega, (1.0 - rho) * omega
+    dg_omega = digamma(omega)
+    e_log_u, e_log_1mu = digamma(g1) - dg_omega, digamma(g0) - dg_omega
+    kv = np.arange(K, 0, -1, dtype=np.float64)
+    if kappa > 0:
+        scale = 1.0
+        on, off = K + 1.0 - g1, K * kv + 1.0 + gamma - g0
+    else:
+        scale = float(n_doc)
+        on, off = 1.0 + (1.0 - g1) / scale, kv + (gamma - g0) / scale
+    ebeta = rho2beta(rho)
+    c_beta = np.sum(gammaln(g1 + g0) - gammaln(g1) - gammaln(g0))
+    elbo = -c_beta / scale + on @ e_log_u + off @ e_log_1mu + ebeta @ T_vec
+    tri_o, tri_1, tri_0 = polygamma(1, omega), polygamma(1, g1), polygamma(1, g0)
+    g_rho = on * omega * tri_1 - off * omega * tri_0
+    g_omega = on * (rho * tri_1 - tri_o) + off * ((1.0 - rho) * tri_0 - tri_o)
+    # d E[beta_j] / d rho_k: E[beta_k] / rho_k on the diagonal, -E[beta_j] / (1 - rho_k) for j > k
+    delta = np.zeros((K, K + 1))
+    for k in range(K):
+        delta[k, k] = ebeta[k] / rho[k]
+        delta[k, k + 1:] = -ebeta[k + 1:] / (1.0 - rho[k])
+    g_rho = g_rho + delta @ T_vec
+    return -elbo, -np.concatenate([g_rho, g_omega])
+
+
+def find_optimum_rho_omega(sum_log_pi, start_alpha_log_pi, n_doc, gamma, alpha, kappa, init_rho=None, init_omega=None):
+    """argmax of the surrogate bound over (rho, omega): K = len(sum_log_pi) - 1 sticks.
+
+    sum_log_pi [K+1]: column sums of E[log pi] over the transition rows; start_alpha_log_pi [K+1]: startAlpha E[log pi_0]."""
+    sum_log_pi = np.asarray(sum_log_pi, dtype=np.float64).reshape(-1)
+    K = sum_log_pi.size - 1
+    if kappa > 0:
+        t_vec = alpha * sum_log_pi + start_alpha_log_pi
+        t_vec[:-1] += np.log(alpha + kappa) - np.log(kappa)
+    else:
+        t_vec = alpha * sum_log_pi / n_doc + np.asarray(start_alpha_log_pi, dtype=np.float64) / n_doc
+    rho0 = create_initrho(K) if init_rho is None else np.asarray(init_rho, dtype=np.float64)
+    rho0 = np.clip(rho0, EPS, 1.0 - EPS)
+    om0 = (n_doc / K + gamma) * np.ones(K) if init_omega is None else np.asarray(init_omega, dtype=np.float64)
+    om0 = np.maximum(om0, EPS)
+    c0 = np.concatenate([-np.log(1.0 / rho0 - 1.0), np.log(om0)])
+
+    def fun(c):
+        rho = np.clip(1.0 / (1.0 + np.exp(-c[:K])), EPS, 1.0 - EPS)
+        omega = np.exp(c[K:])
+        f, g = _objective(np.concatenate([rho, omega]), t_vec, n_doc, gamma, kappa, K)
+        return f, g * np.concatenate([rho * (1.0 - rho), omega])
+
+    last = None
+    for factr in (1e5, 1e7, 1e9, 1e10, 1e11):     # progressively weaker tolerances until one run converges
+        try:
+            with warnings.catch_warnings():
+                warnings.filterwarnings("error", category=RuntimeWarning, message="overflow")
+                c, f, info = scipy.optimize.fmin_l_bfgs_b(fun, c0, factr=factr)
+            if info["warnflag"] > 1:
+                raise ValueError("FAILURE: " + str(info["task"]))
+            rho = np.clip(1.0 / (1.0 + np.exp(-c[:K])), EPS, 1.0 - EPS)
+            return rho, np.exp(c[K:]), f
+        except (ValueError, RuntimeWarning, FloatingPointError) as err:
+            last = err
+    if init_rho is not None:
+        return find_optimum_rho_omega(sum_log_pi, start_alpha_log_pi, n_doc, gamma, alpha, kappa)
+    raise ValueError(str(last))

@@ -423,3 +423,23 @@ def hmm_messages(q, log_pi, log_trans, want_pair=True):
     _ffi.check(_ffi.lib.hgp_hmm_messages_f64(_ptr(q), _ptr(log_pi), _ptr(log_trans), N, K, _ptr(fmsg), _ptr(marg), _ptr(bmsg),
                                              _ptr(pair), _stream()), "hmm_messages")
     return fmsg, marg, bmsg, pair
+
+
+def loglik_rows(q):
+    """GPI_HDP.LogLik(axis=1) on the device: (q - rowmax, rowmax); unchanged input if any row maximum is infinite."""
+    q = _dev64(q, "q")
+    N, K = q.shape
+    out = torch.empty_like(q)
+    rowmax = torch.empty(N, dtype=torch.float64, device=q.device)
+    _ffi.check(_ffi.lib.hgp_loglik_rows_f64(_ptr(q), N, K, _ptr(out), _ptr(rowmax), _stream()), "loglik_rows")
+    return out, rowmax
+
+
+def assign(fmsg, bmsg, want_resp=False):
+    """GPI_HDP._safe_exp(LogLik(log(alpha * beta))): labels [N] int64 (first arg-max per row) and, optionally, the one-hot resp."""
+    fmsg, bmsg = _dev64(fmsg, "fmsg"), _dev64(bmsg, "bmsg")
+    N, K = fmsg.shape
+    labels = torch.empty(N, dtype=torch.int64, device=fmsg.device)
+    resp = torch.empty((N, K), dtype=torch.float64, device=fmsg.device) if want_resp else None
+    _ffi.check(_ffi.lib.hgp_assign_f64(_ptr(fmsg), _ptr(bmsg), N, K, _ptr(labels), _ptr(resp), _stream()), "assign")
+    return (labels, resp) if want_resp else labels

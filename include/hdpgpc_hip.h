@@ -215,6 +215,12 @@ int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, dou
  * in GPI_HDP.py:3645), log_resp_pair[N,K,K] (may be NULL; row 0 = -inf as in the reference).  K <= 64 (-2 above). */
 int hgp_hmm_messages_f64(const double* q, const double* log_pi, const double* log_trans, int N, int K, double* fmsg,
                          double* marg, double* bmsg, double* log_resp_pair, void* stream);
+/* SURVEY 8f-3, assignment tail.  hgp_loglik_rows_f64 = GPI_HDP.LogLik(axis=1) (GPI_HDP.py:632-661): out[n,:] = q[n,:] -
+ * max_k q[n,k], rowmax[n] (may be NULL) = that maximum; if any row maximum is infinite the input is returned unchanged, as the
+ * reference does.  hgp_assign_f64 = GPI_HDP._safe_exp (the one-hot arg-max, GPI_HDP.py:338-343) of log(fmsg * bmsg):
+ * labels[N] (int64, may be NULL) = first arg-max per row, resp[N,K] (may be NULL) = its one-hot row. */
+int hgp_loglik_rows_f64(const double* q, int N, int K, double* out, double* rowmax, void* stream);
+int hgp_assign_f64(const double* fmsg, const double* bmsg, int N, int K, int64_t* labels, double* resp, void* stream);
 /* a10, the same call in full: alpha[T] = G^{-T} G^{-1} y  (= scipy cho_solve((G, True), y) with G = tril(K), GPI.py:1043);
  * quad[1] = || G^{-1} y ||^2 (may be NULL). */
 int hgp_trsv_lower_solve_f64(const double* G, int ld, const double* y, int T, double* alpha, double* quad, void* stream);

@@ -426,6 +426,59 @@ def gen_offline(tag, rec, n, stride):
     print(f"offline_{tag}: N={N} T={T} M={len(models)} counts={[len(g.indexes) for g in models]}")
 
 
+
+# ------------------------------------- drop-in surface: reload_model_from_labels + cluster_new_batch (record 102)
+def gen_reload(tag, rec, n=None):
+    """What hdpgpc/tests/test_offline_multi_output_load.py:74-85 does, on lead 0 with theta injected: rebuild the model from
+    the record's annotation labels (one full_pass_weighted per class), then classify the same batch with the frozen
+    models (cluster_new_batch, learning=False: M x N log_sq_error(i=-1) calls -> LogLik -> forward / backward ->
+    one-hot arg-max)."""
+    data = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:, :, [0]]
+    labels = np.load(os.path.join(REF, "data", "mitbih", f"{rec}_labels.npy"))
+    if n is not None:
+        data, labels = data[:n], labels[:n]
+    data = np.ascontiguousarray(data)
+    N, T, _ = data.shape
+    labels = labels[:N]
+    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data)
+    sigma, gamma = std * 1.0, std * 1.1
+    noise_warp = std * 0.1
+    xb = np.arange(float(T))[:, None]
+    x_trains = np.array([xb] * N)
+    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+                     bound_lengthscale=(1.0, 20.0), ini_gamma=gamma, ini_sigma=sigma, ini_outputscale=300.0,
+                     noise_warp=noise_warp, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
+                     bound_noise_warp=(noise_warp * 0.1, noise_warp * 0.2), warp_updating=False, method_compute_warp="greedy",
+                     verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
+                     inducing_points=False, reestimate_initial_params=True, n_explore_steps=20, free_deg_MNIV=5)
+    labels_trans = {'N': 1, 'V': 2, 'R': 3, '!': 4, 'F': 5, 'L': 6, 'A': 7, '/': 8, 'Q': 9, 'f': 10, 'E': 11, 'J': 12, 'j': 13,
+                    'e': 14, 'a': 15, 'S': 16}
+    labels_num = [labels_trans[l] - 1 for l in labels]
+    vals = np.unique(labels_num)
+    M = vals.shape[0]
+    lab = np.array([np.where(vals == l)[0] for l in labels_num]).squeeze()
+    sw.reload_model_from_labels(x_trains, data, lab, M)
+    new_labels = sw.cluster_new_batch(x_trains, data)
+    out = {"y": data[..., 0], "x_basis": xb[:, 0], "labels": lab.astype(np.int64), "M": np.array(M),
+           "estimators": np.array([std, std_dif, bound_sigma[0], bound_sigma[1], bound_gamma[0], bound_gamma[1]]),
+           "sigma": np.array(sigma), "gamma": np.array(gamma), "theta_inject": np.array(THETA_INJECT),
+           "new_labels": npy(new_labels).astype(np.int64), "transTheta": npy(sw.transTheta), "startTheta": npy(sw.startTheta),
+           "rho": npy(sw.rho), "omega": npy(sw.omega), "q_last": npy(sw.q_last)[:, :, 0], "q_lat_last": npy(sw.q_lat_last)[:, :, 0],
+           "resp_assigned": npy(sw.resp_assigned[-1]).astype(np.int64)}
+    # the q matrix cluster_new_batch scored (frozen last states, i = -1) for diagnostics of the arg-max margin
+    xt, yt = torch.from_numpy(x_trains), torch.from_numpy(data)
+    qn = np.zeros((N, M))
+    for m in range(M):
+        g = sw.gpmodels[0][m]
+        qn[:, m] = [float(g.log_sq_error(xt[i], yt[i], i=-1)) for i in range(N)]
+        out[f"m{m}_theta"] = kernel_theta(g.gp.kernel)
+        out[f"m{m}_n_members"] = np.array(len(g.indexes))
+    out["q_new"] = qn
+    np.savez_compressed(os.path.join(OUT, f"reload_{tag}.npz"), **out)
+    print(f"reload_{tag}: N={N} M={M} counts={[len(g.indexes) for g in sw.gpmodels[0]]} "
+          f"changed labels={int(np.sum(out['new_labels'] != lab))}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gram", "score", "pred", "ill", "state", "lml", "warp", "offline"]
     if "gram" in which:
@@ -448,4 +501,6 @@ if __name__ == "__main__":
         gen_warp_prior()
     if "offline" in which:
         gen_offline("r102_t45", "102", 60, 2)
+    if "reload" in which:
+        gen_reload("r102", "102")
     print("done")

@@ -1,0 +1,92 @@
+"""The drop-in surface (Face 1): `import hdpgpc.GPI_HDP`, `hdpgpc.get_data.compute_estimators_LDS`,
+`hdpgpc.util_plots.print_results` driven exactly as hdpgpc/tests/test_offline_multi_output_load.py:32-85 drives the
+reference (MIT-BIH record 102, lead 0, kernel hyper-parameters injected), against the reference's own results
+(tests/golden/reload_r102.npz): the label tensor of cluster_new_batch must be reproduced EXACTLY."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _driver(g):
+    import hdpgpc.GPI_HDP as hdpgp
+    from hdpgpc.get_data import compute_estimators_LDS
+    data = g["y"][:, :, None]
+    num_samples, num_obs_per_sample, num_outputs = data.shape
+    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data)
+    assert np.allclose([std, std_dif, *bound_sigma, *bound_gamma], g["estimators"], rtol=1e-12)
+    sigma, gamma = std * 1.0, std * 1.1
+    noise_warp = std * 0.1
+    x_basis = np.atleast_2d(np.arange(0, num_obs_per_sample, 1, dtype=np.float64)).T
+    x_basis_warp = np.atleast_2d(np.arange(0, num_obs_per_sample, 2, dtype=np.float64)).T
+    x_trains = np.array([x_basis] * num_samples)
+    sw_gp = hdpgp.GPI_HDP(x_basis, x_basis_warp=x_basis_warp, n_outputs=num_outputs, kernels=None, model_type='dynamic',
+                          ini_lengthscale=3.0, bound_lengthscale=(1.0, 20.0), ini_gamma=gamma, ini_sigma=sigma,
+                          ini_outputscale=300.0, noise_warp=noise_warp, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
+                          bound_noise_warp=(noise_warp * 0.1, noise_warp * 0.2), warp_updating=False,
+                          method_compute_warp='greedy', verbose=False, hmm_switch=True, max_models=100, mode_warp='rough',
+                          bayesian_params=True, inducing_points=False, reestimate_initial_params=True, n_explore_steps=20,
+                          free_deg_MNIV=5)
+    sw_gp.fixed_theta = tuple(float(v) for v in g["theta_inject"])    # in place of the gpytorch fit
+    return sw_gp, x_trains, data
+
+
+def test_reload_from_labels_and_classify_record_102():
+    g = golden("reload_r102.npz")
+    sw_gp, x_trains, data = _driver(g)
+    M = int(g["M"])
+    sw_gp.reload_model_from_labels(x_trains, data, g["labels"], M)
+    assert [len(gp.indexes) for gp in sw_gp.gpmodels[0]] == list(np.bincount(g["labels"], minlength=M))
+    assert np.array_equal(sw_gp.resp_assigned[-1].numpy(), g["resp_assigned"])
+    # the HDP pseudo-counts cluster_new_batch reads (host side; surrogate bound optimised as in the reference)
+    assert np.allclose(sw_gp.transTheta, g["transTheta"], rtol=1e-8) and np.allclose(sw_gp.startTheta, g["startTheta"], rtol=1e-8)
+    assert np.allclose(sw_gp.rho, g["rho"], rtol=1e-7) and np.allclose(sw_gp.omega, g["omega"], rtol=1e-7)
+    # the score matrices of the rebuilt models: 2 187 Kalman / MNIW steps per lead, then a6 / a8
+    assert rel_err(sw_gp.q_last[:, :, 0].cpu().numpy(), g["q_last"]) < 1e-5
+    members = g["q_lat_last"] != 0.0
+    assert rel_err(sw_gp.q_lat_last[:, :, 0].cpu().numpy()[members], g["q_lat_last"][members]) < 1e-5
+    # classification of the batch with the frozen models: the N x M score matrix and the label tensor
+    xt, yt = sw_gp.cond_to_torch(x_trains), sw_gp.cond_to_torch(data)
+    q_new = sw_gp.frozen_scores(xt, yt)[:, :, 0].cpu().numpy()
+    assert rel_err(q_new, g["q_new"]) < 1e-6
+    new_labels = sw_gp.cluster_new_batch(x_trains, data)
+    assert new_labels.dtype == torch.int64
+    assert np.array_equal(new_labels.numpy(), g["new_labels"])           # bit-identical assignments
+    # the drivers' result table runs on the rebuilt models
+    from hdpgpc.util_plots import print_results
+    main_model = print_results(sw_gp, [str(v) for v in g["labels"]], 0, error=False)
+    assert main_model == [str(m) for m in range(M)]
+    assert sw_gp.selected_gpmodels() == list(range(M))
+
+
+def test_frozen_scores_mixed_grids_match_per_segment_calls():
+    """cluster_new_batch's score matrix on a batch that mixes basis-grid and irregular-grid segments equals the per-segment
+    GPI_model.log_sq_error(x, y, i=-1) calls of the reference's double loop (GPI_HDP.py:2981-2985)."""
+    g = golden("reload_r102.npz")
+    sw_gp, x_trains, data = _driver(g)
+    n = 120
+    lab = g["labels"][:n].copy()
+    vals = np.unique(lab)
+    lab = np.searchsorted(vals, lab)
+    sw_gp.reload_model_from_labels(x_trains[:n], data[:n], lab, len(vals))
+    rng = np.random.default_rng(0)
+    xs = x_trains[:12].copy()
+    xs[::2] += rng.uniform(-0.3, 0.3, xs[::2].shape)       # every other segment on an irregular grid
+    q = sw_gp.frozen_scores(sw_gp.cond_to_torch(xs), sw_gp.cond_to_torch(data[:12]))[:, :, 0].cpu().numpy()
+    for m, gp in enumerate(sw_gp.gpmodels[0]):
+        for i in range(12):
+            ref = float(gp.log_sq_error(xs[i], data[i], i=-1))
+            assert abs(q[i, m] - ref) <= 1e-9 * abs(ref), (i, m)
+    assert sw_gp.cluster_new_batch(xs, data[:12]).shape == (12,)
+
+
+def test_control_loop_is_out_of_scope_and_says_so():
+    g = golden("reload_r102.npz")
+    sw_gp, x_trains, data = _driver(g)
+    with pytest.raises(NotImplementedError):
+        sw_gp.include_batch(x_trains[:4], data[:4], with_warp=False)
+    with pytest.raises(NotImplementedError):
+        sw_gp.include_sample(x_trains[0], data[0], with_warp=False)
