@@ -238,14 +238,19 @@ class GPI_model:
         self.observation_params = matrix_normal_inv_wishart(ini_C, None, self.free_deg_MNIV, ini_Sigma)
 
     def fit_kernel_params(self, x_train, y, alpha_ini, gamma_ini, valid=True):
-        """GPI_model.py:207-241 with the gpytorch fit (GPI.py:610-770) replaced by ``self.fixed_theta``: what the fit
-        leaves behind is outputscale, a length-scale forced to 1.2 (GPI.py:711) and a noise level clamped to its
-        bounds - and none of them enters Sigma, which is reset to the INITIAL sigma (GPI_model.py:215-219)."""
+        """GPI_model.py:207-241.  The gpytorch fit (GPI.py:610-770) is either replaced by ``self.fixed_theta`` (what the
+        golden fixtures inject) or restated by kernel_fit.fit_kernel_adam: what the fit leaves behind is outputscale, a
+        length-scale forced to 1.2 (GPI.py:711) and a noise level inside its bounds - and none of them enters Sigma, which
+        is reset to the INITIAL sigma (GPI_model.py:215-219)."""
         if valid:
-            if self.fixed_theta is None:
-                raise NotImplementedError("kernel hyper-parameter fit (gpytorch) is out of scope: set GPI_model.fixed_theta")
-            c, ell, noise = self.fixed_theta
             lo, hi = self.noise_bounds
+            if self.fixed_theta is None:      # SURVEY.md 8f-2: Adam on the exact MLL of this first member (kernel_fit.py)
+                from .kernel_fit import fit_kernel_adam
+                c, _, noise, _ = fit_kernel_adam(self.x_basis.reshape(-1).cpu().numpy(), self.cond_to_torch(y).reshape(-1).cpu().numpy(),
+                                                 (lo, hi), device=self.device)
+                ell = 1.2                     # GPI.py:711 overwrites the fitted length-scale
+            else:
+                c, ell, noise = self.fixed_theta
             k = self.gp.kernel
             k.constant_value, k.length_scale, k.noise_level = float(c), float(ell), float(min(max(noise, lo), hi))
             self.gp.fitted = True
@@ -336,7 +341,7 @@ class GPI_model:
             raise NotImplementedError("producer recursion: shared grid only")
         if h == 1.0:
             if self.N == 0 and not self.fitted:
-                self.fit_kernel_params(x_train, y, self.Sigma[-1], self.Gamma[-1], valid=self.fixed_theta is not None)
+                self.fit_kernel_params(x_train, y, self.Sigma[-1], self.Gamma[-1], valid=True)
             self.include_sample(index, x_train, y, x_warped, h=1.0)
         else:
             self.include_sample(index, x_train, y, x_warped, posterior=False)
