@@ -290,24 +290,106 @@ class GPI_model:
                 what = pending[int(np.searchsorted(sizes, flat, side="right"))][0]      # flat index -> its entry
                 raise torch.linalg.LinAlgError(f"{what}: the input is not positive-definite")
 
-    def _posterior(self, mean_prior, cov_prior, y, A, Gamma, C, Sigma, first_step, h=1.0):
-        """GPI.posterior (GPI.py:72-151) on the shared grid (x_warped == x_basis, K_cov = I)."""
+    def _posterior(self, mean_prior, cov_prior, y, A, Gamma, C, Sigma, first_step, h=1.0, x_warped=None):
+        """GPI.posterior (GPI.py:72-151).  x_warped None / equal to the basis: K_cov = I (shared grid); otherwise the
+        observation sits on its own grid and K_cov = K(x, xb) (K(xb, xb) + 1e-4 I)^{-1} interpolates the basis state onto it
+        (GPI.py:124-133), f*, cov_f come from pred_dist (GPI.py:141-142)."""
         mm = ops.gemm_batched
         xm = mm(A, mean_prior)
+        on_basis = x_warped is None or (x_warped.shape == self.x_basis.shape and bool(torch.equal(x_warped, self.x_basis)))
+        k = self.gp.kernel
         if first_step:   # cov_prior is the kernel Gram itself (GPI.py:136-139): prior predictive, white-noise observation
             P = cov_prior
-            f_star = torch.zeros_like(xm)
-            k = self.gp.kernel   # kernel(x) - kernel(x, x): the white-noise level as the reference's subtraction leaves it
-            cov_f = (((k.constant_value + k.noise_level) - k.constant_value) / h) * self._eye()
+            n_obs = self.x_basis.shape[0] if on_basis else x_warped.shape[0]
+            f_star = torch.zeros((n_obs, 1), dtype=f64, device=self.device)
+            # kernel(x) - kernel(x, x): the white-noise level as the reference's subtraction leaves it
+            cov_f = (((k.constant_value + k.noise_level) - k.constant_value) / h) * torch.eye(n_obs, dtype=f64, device=self.device)
         else:
             P = mm(mm(A, cov_prior), A, transB=True) + Gamma
-            f_star, cov_f = mm(C, xm), Sigma                  # pred_dist short-circuits on the shared grid (GPI.py:467-468)
-        S = mm(mm(C, P), C, transB=True) + cov_f
-        K_t = mm(mm(P, C, transB=True), self._spd_inv(S, "posterior"))   # P C^T S^{-1} (GPI.py:144-145); the inverse symmetrises on load
+            if on_basis:
+                f_star, cov_f = mm(C, xm), Sigma              # pred_dist short-circuits on the shared grid (GPI.py:467-468)
+            else:
+                f_star, cov_f = self.gp.pred_dist(x_warped, self.x_basis, mm(C, xm), Sigma)
+        if on_basis:
+            KC = C
+        else:
+            T = self.x_basis.shape[0]
+            Kxx = k(self.x_basis, self.x_basis) + 1e-4 * self._eye()
+            Kinv = self._spd_inv(Kxx, "posterior (K_cov)")
+            KC = mm(mm(k(x_warped, self.x_basis), Kinv), C)    # K_cov C, [T*, T]
+        S = mm(mm(KC, P), KC, transB=True) + cov_f
+        K_t = mm(mm(P, KC, transB=True), self._spd_inv(S, "posterior"))   # P KC^T S^{-1} (GPI.py:144-145); the inverse symmetrises on load
         mean_post = xm + mm(K_t, y - f_star)
-        IKC = self._eye() - mm(K_t, C)
+        IKC = self._eye() - mm(K_t, KC)
         cov_post = mm(mm(IKC, P), IKC, transB=True) + mm(mm(K_t, cov_f.contiguous()), K_t, transB=True)   # Joseph form
         return mean_post, cov_post
+
+    def posterior_weighted(self, x_train, y, h, t=None):
+        """GPI_model.py:561-582: the filtered state the model would have after absorbing (x, y) with responsibility h -
+        from the last FILTERED state (or the one of step t), with Gamma / h and Sigma / h."""
+        y = self.cond_to_torch(y).reshape(-1, 1)
+        x = self.cond_to_torch(x_train).reshape(-1, 1)
+        if not h > 0.0:
+            return self.f_star[-1].clone(), self.cov_f[-1].clone()
+        if t is not None and len(self.indexes) > t:
+            f, c = self.f_star[t], self.cov_f[t]
+            A, Gamma, C, Sigma = self.get_params(t)
+        else:
+            f, c, A, Gamma, C, Sigma = self.f_star[-1], self.cov_f[-1], self.A[-1], self.Gamma[-1], self.C[-1], self.Sigma[-1]
+        first = bool(torch.equal(c, self.gp.kernel(self.x_basis, self.x_basis)))
+        out = self._posterior(f, c, y, A, Gamma / h, C, Sigma / h, first, h=h, x_warped=x)
+        self._check_pending()
+        return out
+
+    def find_closest_lower(self, t):
+        """GPI_model.py:584-593: position of the last member at or before segment t (the index list is sorted)."""
+        idx = int(np.searchsorted(np.asarray(self.indexes, dtype=np.int64), t, side="right"))
+        return idx - 1 if idx else 0
+
+    def smoother_weighted(self, x_train, y, h):
+        """GPI_model.py:726-738: the state lists as they would be with the sample added (nothing is stored)."""
+        f_aux, c_aux = self.posterior_weighted(x_train, y, h)
+        return self.f_star + [f_aux], self.cov_f + [c_aux], self.C + [self.C[-1]], self.Sigma + [self.Sigma[-1]]
+
+    def smoother_weighted_index(self, x_train, y, h, t):
+        """GPI_model.py:740-745."""
+        f_aux, c_aux = self.posterior_weighted(x_train, y, h, t)
+        _, _, C, Sigma = self.get_params(t)
+        return f_aux, c_aux, C, Sigma
+
+    def reinit_GP(self, save_last=False, save_index=False):
+        """GPI_model.py:408-434: drop the filtered / smoothed history (keep the first entry, or first and last)."""
+        if save_last:
+            self.f_star = [self.f_star[0], self.f_star[-1]]
+            self.f_star_sm = [self.f_star[0].clone(), self.f_star[-1].clone()]
+            self.cov_f = [self.cov_f[0], self.cov_f[-1]]
+            self.cov_f_sm = [self.cov_f_sm[0], self.cov_f_sm[-1]]
+            if not save_index:
+                self.indexes = [0]
+        else:
+            self.f_star = self.f_star[:1]
+            self.f_star_sm = list(self.f_star)
+            self.cov_f = [self.ini_cov_def.clone()]
+            self.cov_f_sm = [self.ini_cov_def.clone()]
+            self.indexes = []
+        self.y_train, self.x_train = [], []
+        self.N = 0
+        self._stk = {}
+
+    def reinit_LDS(self, save_last=False, save_last_diag=False):
+        """GPI_model.py:437-457: back to the default LDS parameters (or keep the last ones) and fresh MNIW priors."""
+        if save_last:
+            if save_last_diag:
+                ini = (self.A_def, torch.diag(torch.diagonal(self.Gamma[-1])) * 3.0, self.C_def, torch.diag(torch.diagonal(self.Sigma[-1])) * 3.0)
+            else:
+                ini = (self.A[-1], self.Gamma[-1], self.C[-1], self.Sigma[-1])
+        else:
+            ini = (self.A_def, self.Gamma_def, self.C_def, self.Sigma_def)
+        self.A, self.Gamma, self.C, self.Sigma = [ini[0]], [ini[1]], [ini[2]], [ini[3]]
+        eye = self._eye()
+        self.internal_params = matrix_normal_inv_wishart(ini[0], eye, self.free_deg_MNIV, ini[1])
+        self.observation_params = matrix_normal_inv_wishart(ini[2], eye, self.free_deg_MNIV, ini[3])
+        self._stk = {}
 
     def include_sample(self, index, x_train, y, x_warped=None, h=1.0, posterior=True, embedding=True, include_index=False):
         """GPI_model.py:325-351."""
@@ -320,8 +402,9 @@ class GPI_model:
             # GPI.py:136 tests cov_prior == ker(xb, xb) on every call (two Gram builds per step); it can only hold for
             # the first member after the kernel fit, so it is only evaluated there
             first = self.N == 1 and bool(torch.equal(self.cov_f_sm[-1], self.gp.kernel(self.x_basis, self.x_basis)))
+            xw = None if x_warped is None else self.cond_to_torch(x_warped).reshape(-1, 1)
             f, c = self._posterior(self.f_star_sm[-1], self.cov_f_sm[-1], y, self.A[-1], self.Gamma[-1], self.C[-1],
-                                   self.Sigma[-1] / h, first, h)
+                                   self.Sigma[-1] / h, first, h, x_warped=xw)
         elif include_index:
             self.indexes.append(int(index))
             self.x_train.append(x_train)
@@ -337,8 +420,6 @@ class GPI_model:
         if snr is not None:
             raise NotImplementedError("snr-gated inclusion (multi-lead) is not part of this path")
         x_train = self.cond_to_torch(x_train).reshape(-1, 1)
-        if not torch.equal(x_train, self.x_basis):
-            raise NotImplementedError("producer recursion: shared grid only")
         if h == 1.0:
             if self.N == 0 and not self.fitted:
                 self.fit_kernel_params(x_train, y, self.Sigma[-1], self.Gamma[-1], valid=True)

@@ -479,6 +479,43 @@ def gen_reload(tag, rec, n=None):
           f"changed labels={int(np.sum(out['new_labels'] != lab))}")
 
 
+# ------------------------------------------------ online-side producer pieces on a real state (GPI_model.py:561-593,726-745)
+def gen_producer_extra():
+    """posterior_weighted / smoother_weighted (what GPI_HDP.estimate_new calls, GPI_HDP.py:2830-2841) on the state of the
+    t45 fixture: shared grid and irregular grid (the K_cov path of GPI.posterior, GPI.py:124-133,144-146), h = 1 and h < 1;
+    then reinit_LDS / reinit_GP and a second pass over other members."""
+    rng = np.random.default_rng(31)
+    data = load_beats("102", 24, 2)
+    members = [0, 1, 2, 3, 4, 7, 8, 11, 15, 16, 20]
+    gm, x_trains, y_trains, q, q_lat = build_model(data, members)
+    n, T, _ = data.shape
+    x_irr = np.arange(float(T))[:, None] + rng.uniform(-0.3, 0.3, (T, 1))
+    out = {"x_irr": x_irr[:, 0], "y_new": data[21, :, 0]}
+    for tag, xx in (("shared", npy(x_trains[21])), ("irr", x_irr)):
+        for h in (1.0, 0.6):
+            f, c = gm.posterior_weighted(torch.from_numpy(xx), y_trains[21], h)
+            out[f"pw_{tag}_h{h}_f"], out[f"pw_{tag}_h{h}_cov"] = npy(f)[:, 0], npy(c)
+        f, c = gm.posterior_weighted(torch.from_numpy(xx), y_trains[21], 1.0, t=3)
+        out[f"pw_{tag}_t3_f"], out[f"pw_{tag}_t3_cov"] = npy(f)[:, 0], npy(c)
+    means, covs, C, Sigma = gm.smoother_weighted(x_trains[21], y_trains[21], 1.0)
+    out["sw_len"] = np.array([len(means), len(covs), len(C), len(Sigma)])
+    out["sw_last_f"], out["sw_last_cov"] = npy(means[-1])[:, 0], npy(covs[-1])
+    # estimate_new's score: log_sq_error with the smoothed candidate as params, first=True (GPI_HDP.py:2835-2841)
+    out["lse_candidate"] = np.array(float(gm.log_sq_error(x_trains[21], y_trains[21], mean=means[-1], cov=covs[-1], C=C[-1],
+                                                          Sigma=Sigma[-1], i=0, first=True)))
+    # re-initialise and run another member set through the SAME (fitted) model
+    gm.reinit_LDS(save_last=False)
+    gm.reinit_GP(save_last=False)
+    out["re_N"], out["re_fitted"] = np.array(gm.N), np.array(int(gm.fitted))
+    resp = torch.zeros(n)
+    resp[[5, 6, 9, 10, 12]] = 1.0
+    q2, ql2 = gm.full_pass_weighted(x_trains, y_trains, resp)
+    out["re_q"], out["re_q_lat"] = npy(q2), npy(ql2)
+    out["re_Sigma_last"], out["re_f_sm_last"] = npy(gm.Sigma[-1]), npy(gm.f_star_sm[-1])[:, 0]
+    np.savez_compressed(os.path.join(OUT, "producer_extra.npz"), **out)
+    print("producer_extra: done")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gram", "score", "pred", "ill", "state", "lml", "warp", "offline"]
     if "gram" in which:
@@ -501,6 +538,8 @@ if __name__ == "__main__":
         gen_warp_prior()
     if "offline" in which:
         gen_offline("r102_t45", "102", 60, 2)
+    if "extra" in which:
+        gen_producer_extra()
     if "reload" in which:
         gen_reload("r102", "102")
     print("done")

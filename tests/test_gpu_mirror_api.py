@@ -232,6 +232,51 @@ def test_pending_info_names_the_failing_step():
     assert m._pending == []
 
 
+def test_online_side_producer_pieces():
+    """posterior_weighted / smoother_weighted (GPI_model.py:561-582,726-738: what GPI_HDP.estimate_new calls) on the shared
+    grid and on an irregular grid (the K_cov path of GPI.posterior, GPI.py:124-133), h = 1 and h < 1, then
+    reinit_LDS / reinit_GP and a second pass through the same fitted model - against the reference's outputs."""
+    g, e = golden("state_t45.npz"), golden("producer_extra.npz")
+    y = g["y"]
+    n, T = y.shape
+    members = [int(v) for v in g["st_indexes"]]
+    sigma, gamma = float(g["st_Sigma"][0][0, 0]), float(g["st_Gamma"][0][0, 0])
+    m = GPI_model(RBFWhiteKernel(300.0, 3.0, sigma * 1e-5), g["st_x_basis"][:, None], annealing=True, bayesian=True, free_deg_MNIV=5)
+    cond = m.GPR_dynamic(gamma, sigma)
+    m.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
+    m.fixed_theta = tuple(float(v) for v in g["st_theta"])
+    xs = np.repeat(g["st_x_basis"][None, :, None], n, axis=0)
+    resp = np.zeros(n)
+    resp[members] = 1.0
+    m.full_pass_weighted(xs, y[:, :, None], resp)
+    tol = 1e-6
+
+    def close(a, b):
+        return np.allclose(a, b, rtol=tol, atol=tol * np.abs(b).max())
+
+    for tag, xx in (("shared", xs[21]), ("irr", e["x_irr"][:, None])):
+        for h in (1.0, 0.6):
+            f, c = m.posterior_weighted(xx, y[21][:, None], h)
+            assert close(f.cpu().numpy()[:, 0], e[f"pw_{tag}_h{h}_f"]) and close(c.cpu().numpy(), e[f"pw_{tag}_h{h}_cov"]), (tag, h)
+        f, c = m.posterior_weighted(xx, y[21][:, None], 1.0, t=3)
+        assert close(f.cpu().numpy()[:, 0], e[f"pw_{tag}_t3_f"]) and close(c.cpu().numpy(), e[f"pw_{tag}_t3_cov"]), tag
+    means, covs, C, Sigma = m.smoother_weighted(xs[21], y[21][:, None], 1.0)
+    assert [len(means), len(covs), len(C), len(Sigma)] == list(e["sw_len"])
+    assert close(means[-1].cpu().numpy()[:, 0], e["sw_last_f"]) and close(covs[-1].cpu().numpy(), e["sw_last_cov"])
+    v = m.log_sq_error(xs[21], y[21][:, None], mean=means[-1], cov=covs[-1], C=C[-1], Sigma=Sigma[-1], i=0, first=True)
+    assert abs(float(v) - float(e["lse_candidate"])) <= tol * abs(float(e["lse_candidate"]))
+    assert m.find_closest_lower(0) == 0 and m.find_closest_lower(6) == 4 and m.find_closest_lower(23) == len(members) - 1
+    m.reinit_LDS(save_last=False)
+    m.reinit_GP(save_last=False)
+    assert m.N == int(e["re_N"]) and int(m.fitted) == int(e["re_fitted"]) and m.indexes == []
+    resp = np.zeros(n)
+    resp[[5, 6, 9, 10, 12]] = 1.0
+    q2, ql2 = m.full_pass_weighted(xs, y[:, :, None], resp)
+    assert rel_err(q2.cpu().numpy(), e["re_q"]) < 1e-6
+    assert rel_err(ql2.cpu().numpy()[[5, 6, 9, 10, 12]], e["re_q_lat"][[5, 6, 9, 10, 12]]) < 1e-6
+    assert close(m.Sigma[-1].cpu().numpy(), e["re_Sigma_last"]) and close(m.f_star_sm[-1].cpu().numpy()[:, 0], e["re_f_sm_last"])
+
+
 def test_replay_offline_trace_from_labels():
     """labels -> recursion -> q matrix -> hard assignments, on the reference's own include_batch result (record 102,
     60 beats, T = 45, 5 clusters): a fresh model per cluster is driven over the cluster's final members and must end
