@@ -52,6 +52,7 @@ def _load():
         "hgp_hmm_messages_f64": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
         "hgp_loglik_rows_f64": (i32, [vp, i32, i32, vp, vp, vp]),
         "hgp_assign_f64": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+        "hgp_warp_batch_f64": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp, vp, vp]),
         "hgp_trsv_lower_solve_f64": (i32, [vp, i32, vp, i32, vp, vp, vp]),
         "hgp_lml_grad_f64": (i32, [vp, vp, vp, i32, f64, f64, f64, vp, vp]),
     }

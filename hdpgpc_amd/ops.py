@@ -443,3 +443,22 @@ def assign(fmsg, bmsg, want_resp=False):
     resp = torch.empty((N, K), dtype=torch.float64, device=fmsg.device) if want_resp else None
     _ffi.check(_ffi.lib.hgp_assign_f64(_ptr(fmsg), _ptr(bmsg), N, K, _ptr(labels), _ptr(resp), _stream()), "assign")
     return (labels, resp) if want_resp else labels
+
+
+def warp_batch(x, Yt, Ym, n_ctrl, iters, noise, lam_s, lam_a, lr, weights=None, u0=None, want_trace=True):
+    """8f-4: B monotone time-warps fitted by Adam in one launch.  x [T]; Yt [B,T,D]; Ym [T,D] (shared) or [B,T,D].
+    Returns (u [B,n_ctrl], x_warp [B,T], y_warp [B,T,D], trace [B,iters,4] or None)."""
+    x, Yt, Ym = _dev64(x.reshape(-1), "x"), _dev64(Yt, "Yt"), _dev64(Ym, "Ym")
+    B, T, D = Yt.shape
+    stride = 0 if Ym.dim() == 2 else T * D
+    dev = x.device
+    w = None if weights is None else _dev64(weights.reshape(B), "weights")
+    u0 = None if u0 is None else _dev64(u0.reshape(n_ctrl), "u0")
+    u = torch.empty((B, n_ctrl), dtype=torch.float64, device=dev)
+    xw = torch.empty((B, T), dtype=torch.float64, device=dev)
+    yw = torch.empty((B, T, D), dtype=torch.float64, device=dev)
+    tr = torch.empty((B, iters, 4), dtype=torch.float64, device=dev) if want_trace else None
+    _ffi.check(_ffi.lib.hgp_warp_batch_f64(_ptr(x), _ptr(Yt), _ptr(Ym), stride, T, B, D, int(n_ctrl), int(iters), float(noise),
+                                           float(lam_s), float(lam_a), float(lr), _ptr(w), _ptr(u0), _ptr(u), _ptr(xw), _ptr(yw),
+                                           _ptr(tr), _stream()), "warp_batch")
+    return u, xw, yw, tr

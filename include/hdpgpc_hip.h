@@ -221,6 +221,18 @@ int hgp_hmm_messages_f64(const double* q, const double* log_pi, const double* lo
  * labels[N] (int64, may be NULL) = first arg-max per row, resp[N,K] (may be NULL) = its one-hot row. */
 int hgp_loglik_rows_f64(const double* q, int N, int K, double* out, double* rowmax, void* stream);
 int hgp_assign_f64(const double* fmsg, const double* bmsg, int N, int K, int64_t* labels, double* resp, void* stream);
+/* SURVEY 8f-4 - Warping_system.compute_warp_batch (amtgp_warping_system.py:548-735): B independent monotone time-warps
+ * g_b(t) of the observations Yt[b] onto the model mean Ym, each parameterised by n_ctrl control values (softplus increments,
+ * cumulative sum, normalised to the grid's range) and fitted by `iters` Adam steps (lr, torch defaults) on
+ *   0.5 |Yt[b](g_b) - Ym|^2 / (noise + 1e-12) + lam_s |D2 (g_b - x)|^2 + lam_a |g_b - x|^2,
+ * weighted by weights[b] / sum(weights) (NULL = uniform).  One wavefront per sample, the whole optimisation in one launch.
+ * x[T] strictly increasing (T <= 256), Yt[B,T,D], Ym with batch stride ym_stride (0 = one mean shared by the batch), D <= 4,
+ * n_ctrl <= 32; u0[n_ctrl] (may be NULL = zeros) is the warm start of every sample.  Outputs: u_out[B,n_ctrl], xw_out[B,T] =
+ * g_b - x, yw_out[B,T,D] = Yt[b](g_b), loss_out[B,iters,4] (may be NULL) = per-sample loss, data, smoothness and amplitude terms
+ * at every iteration.  The warp-prior score of the result is hgp_warp_cov_f64 + hgp_score_groups_f64 (a11). */
+int hgp_warp_batch_f64(const double* x, const double* Yt, const double* Ym, long ym_stride, int T, int B, int D, int n_ctrl,
+                       int iters, double noise, double lam_s, double lam_a, double lr, const double* weights, const double* u0,
+                       double* u_out, double* xw_out, double* yw_out, double* loss_out, void* stream);
 /* a10, the same call in full: alpha[T] = G^{-T} G^{-1} y  (= scipy cho_solve((G, True), y) with G = tril(K), GPI.py:1043);
  * quad[1] = || G^{-1} y ||^2 (may be NULL). */
 int hgp_trsv_lower_solve_f64(const double* G, int ld, const double* y, int T, double* alpha, double* quad, void* stream);

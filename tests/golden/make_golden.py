@@ -63,7 +63,7 @@ import hdpgpc.GPI as GPI  # noqa: E402
 import hdpgpc.GPI_model as GM  # noqa: E402
 import hdpgpc.GPI_HDP as HDP  # noqa: E402
 from hdpgpc.get_data import compute_estimators_LDS  # noqa: E402
-from hdpgpc.amtgp_warping_system import WarpPriorAMTGP  # noqa: E402
+from hdpgpc.amtgp_warping_system import WarpPriorAMTGP, Warping_system  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, ConstantKernel, WhiteKernel  # noqa: E402
 
 
@@ -516,6 +516,47 @@ def gen_producer_extra():
     print("producer_extra: done")
 
 
+# ------------------------------------------------------------- 8f-4: batched monotone time-warp fit (WARP:548-735)
+def gen_warp_batch():
+    """Warping_system.compute_warp_batch: B independent warps fitted by Adam (torch autograd in the reference) - inputs, the
+    warps, the warped observations, the prior scores and the per-iteration mean losses."""
+    rng = np.random.default_rng(41)
+    out = {}
+    i = 0
+    for (T, B, D, iters, theta, recursive) in [(90, 7, 1, 50, 1.2, False), (90, 5, 1, 250, (0.8, 1.5), False),
+                                               (45, 4, 2, 60, None, True), (128, 3, 1, 40, 1.2, False)]:
+        x = np.arange(float(T)) if T != 45 else np.arange(float(T)) * 2.0
+        t = x / x[-1]
+        base = np.stack([80 * np.exp(-0.5 * ((t - 0.45) / 0.05) ** 2) - 30 * np.exp(-0.5 * ((t - 0.6) / 0.08) ** 2) + 5 * d
+                         for d in range(D)], axis=1)                                    # (T, D) cluster mean
+        Yt = np.zeros((B, T, D))
+        for b in range(B):
+            shift = rng.uniform(-0.06, 0.06)
+            tw = np.clip(t + shift * np.sin(np.pi * t), 0, 1)
+            for d in range(D):
+                Yt[b, :, d] = np.interp(tw, t, base[:, d]) + rng.normal(0, 1.0, T)
+        noise = rng.uniform(1.0, 3.0, T)
+        wgt = None if i != 2 else rng.uniform(0.2, 1.0, B)
+        ws = Warping_system(x[:, None], noise_warp=0.5, bound_noise_warp=(0.05, 5.0), recursive=recursive, bayesian=True,
+                            cuda=False, mode="rough")
+        reps = 2 if recursive else 1                       # second call starts from the first call's mean control vector
+        for rep in range(reps):
+            xw, yw, lik, tr = ws.compute_warp_batch(torch.from_numpy(x), torch.from_numpy(Yt), torch.from_numpy(base), theta=theta,
+                                                    noise=torch.from_numpy(noise), weights=None if wgt is None else torch.from_numpy(wgt),
+                                                    train_iter=iters)
+            out[f"c{i}_r{rep}_xw"], out[f"c{i}_r{rep}_yw"], out[f"c{i}_r{rep}_lik"] = npy(xw)[:, :, 0], npy(yw), npy(lik)
+            out[f"c{i}_r{rep}_loss"] = np.array(tr["loss"])
+        out[f"c{i}_x"], out[f"c{i}_Yt"], out[f"c{i}_Ym"], out[f"c{i}_noise"] = x, Yt, base, noise
+        out[f"c{i}_theta"] = np.array([np.nan, np.nan]) if theta is None else np.atleast_1d(np.asarray(theta, dtype=np.float64))
+        out[f"c{i}_meta"] = np.array([iters, int(recursive), reps, ws.n_ctrl, ws.lr, ws.lambda_smooth_base, ws.lambda_amp_base, 0.5, 0.05, 5.0])
+        if wgt is not None:
+            out[f"c{i}_w"] = wgt
+        i += 1
+    out["n_cases"] = np.array(i)
+    np.savez_compressed(os.path.join(OUT, "warp_batch.npz"), **out)
+    print(f"warp_batch: {i} cases")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gram", "score", "pred", "ill", "state", "lml", "warp", "offline"]
     if "gram" in which:
@@ -538,6 +579,8 @@ if __name__ == "__main__":
         gen_warp_prior()
     if "offline" in which:
         gen_offline("r102_t45", "102", 60, 2)
+    if "warpbatch" in which:
+        gen_warp_batch()
     if "extra" in which:
         gen_producer_extra()
     if "reload" in which:
