@@ -557,6 +557,37 @@ def gen_warp_batch():
     print(f"warp_batch: {i} cases")
 
 
+# --------------------------------------------- configs[4]: the online path's calls at T = 256 (beats resampled)
+def gen_online_t256():
+    """BASELINE configs[4] runs the online path on beats resampled to T = 256.  What one online step asks of a cluster
+    (GPI_HDP.py:1970-2197): compute_q_lat_all, log_sq_error(i=-1), return_LDS_param_likelihood, the candidate posterior
+    (posterior_weighted / smoother_weighted) - on a state the reference builds itself from 6 members.  Only inputs and
+    final outputs are stored (the mirror rebuilds the state from the beats)."""
+    rng = np.random.default_rng(51)
+    raw = load_beats("102", 10, 1)[..., 0]                                   # (10, 90)
+    T = 256
+    tt = np.linspace(0, raw.shape[1] - 1, T)
+    data = np.stack([np.interp(tt, np.arange(raw.shape[1]), r) for r in raw])[:, :, None]
+    members = [0, 1, 2, 4, 5, 7]
+    gm, x_trains, y_trains, q, q_lat = build_model(np.ascontiguousarray(data), members)
+    n = data.shape[0]
+    x_irr = np.arange(float(T))[None, :, None] + rng.uniform(-0.3, 0.3, (n, T, 1))
+    out = {"y": data[..., 0], "members": np.array(members), "theta": kernel_theta(gm.gp.kernel),
+           "sigma0": npy(gm.Sigma[0])[0, 0], "gamma0": npy(gm.Gamma[0])[0, 0], "x_irr": x_irr[..., 0],
+           "q_shared": npy(q), "q_lat": npy(q_lat), "lds_lik": np.array(float(gm.return_LDS_param_likelihood())),
+           "lse_last_shared": np.array([float(gm.log_sq_error(x_trains[j], y_trains[j], i=-1)) for j in range(n)]),
+           "lse_last_irr": np.array([float(gm.log_sq_error(torch.from_numpy(x_irr[j]), y_trains[j], i=-1)) for j in (8, 9)]),
+           "Sigma_last_diag": np.diag(npy(gm.Sigma[-1])), "Sigma_last_row7": npy(gm.Sigma[-1])[7],
+           "f_star_sm_last": npy(gm.f_star_sm[-1])[:, 0], "n0": np.array(float(gm.internal_params.n0))}
+    f, c = gm.posterior_weighted(x_trains[8], y_trains[8], 1.0)
+    out["pw_f"], out["pw_cov_diag"], out["pw_cov_row100"] = npy(f)[:, 0], np.diag(npy(c)), npy(c)[100]
+    means, covs, C, Sigma = gm.smoother_weighted(x_trains[8], y_trains[8], 1.0)
+    out["lse_candidate"] = np.array(float(gm.log_sq_error(x_trains[8], y_trains[8], mean=means[-1], cov=covs[-1], C=C[-1],
+                                                          Sigma=Sigma[-1], i=0, first=True)))
+    np.savez_compressed(os.path.join(OUT, "online_t256.npz"), **out)
+    print("online_t256: done", out["q_shared"][:3])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gram", "score", "pred", "ill", "state", "lml", "warp", "offline"]
     if "gram" in which:
@@ -579,6 +610,8 @@ if __name__ == "__main__":
         gen_warp_prior()
     if "offline" in which:
         gen_offline("r102_t45", "102", 60, 2)
+    if "online256" in which:
+        gen_online_t256()
     if "warpbatch" in which:
         gen_warp_batch()
     if "extra" in which:

@@ -375,3 +375,44 @@ def test_hmm_messages_8f3_golden_and_large():
     fin = np.isfinite(cr)
     cg = c.cpu().numpy()
     assert np.array_equal(np.isfinite(cg), fin) and np.allclose(cg[fin], cr[fin], rtol=1e-8, atol=1e-8)
+
+
+def test_online_path_calls_at_T256():
+    """BASELINE configs[4]: the online path on beats resampled to T = 256.  The mirror builds the cluster state itself
+    (Kalman / RTS / MNIW recursion on the cooperative T > 128 kernels) and answers what one online step asks of a cluster
+    (GPI_HDP.py:1970-2197): compute_q_lat_all, log_sq_error(i=-1) on the shared and on an irregular grid,
+    return_LDS_param_likelihood, the candidate posterior - against the reference's own outputs."""
+    g = golden("online_t256.npz")
+    y = g["y"]
+    n, T = y.shape
+    assert T == 256
+    members = [int(v) for v in g["members"]]
+    sigma, gamma = float(g["sigma0"]), float(g["gamma0"])
+    m = GPI_model(RBFWhiteKernel(300.0, 3.0, sigma * 1e-5), np.arange(float(T))[:, None], annealing=True, bayesian=True, free_deg_MNIV=5)
+    cond = m.GPR_dynamic(gamma, sigma)
+    m.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
+    m.fixed_theta = tuple(float(v) for v in g["theta"])
+    xs = np.repeat(np.arange(float(T))[None, :, None], n, axis=0)
+    resp = np.zeros(n)
+    resp[members] = 1.0
+    q, q_lat = m.full_pass_weighted(xs, y[:, :, None], resp)
+    tol = 1e-6
+    assert m.indexes == members and float(m.internal_params.n0) == float(g["n0"])
+    assert rel_err(q.cpu().numpy(), g["q_shared"]) < tol
+    assert rel_err(q_lat.cpu().numpy()[members], g["q_lat"][members]) < tol
+    S = m.Sigma[-1].cpu().numpy()
+    assert np.allclose(np.diag(S), g["Sigma_last_diag"], rtol=tol) and np.allclose(S[7], g["Sigma_last_row7"], rtol=tol, atol=tol * np.abs(S).max())
+    assert np.allclose(m.f_star_sm[-1].cpu().numpy()[:, 0], g["f_star_sm_last"], rtol=tol, atol=tol * np.abs(g["f_star_sm_last"]).max())
+    assert abs(float(m.return_LDS_param_likelihood()) - float(g["lds_lik"])) <= tol * abs(float(g["lds_lik"]))
+    for j in (0, 8, 9):
+        assert abs(float(m.log_sq_error(xs[j], y[j][:, None], i=-1)) - g["lse_last_shared"][j]) <= tol * abs(g["lse_last_shared"][j])
+    for k, j in enumerate((8, 9)):
+        v = float(m.log_sq_error(g["x_irr"][j][:, None], y[j][:, None], i=-1))
+        assert abs(v - g["lse_last_irr"][k]) <= tol * abs(g["lse_last_irr"][k])
+    f, c = m.posterior_weighted(xs[8], y[8][:, None], 1.0)
+    c = c.cpu().numpy()
+    assert np.allclose(f.cpu().numpy()[:, 0], g["pw_f"], rtol=tol, atol=tol * np.abs(g["pw_f"]).max())
+    assert np.allclose(np.diag(c), g["pw_cov_diag"], rtol=tol) and np.allclose(c[100], g["pw_cov_row100"], rtol=tol, atol=tol * np.abs(c).max())
+    means, covs, C, Sigma = m.smoother_weighted(xs[8], y[8][:, None], 1.0)
+    v = m.log_sq_error(xs[8], y[8][:, None], mean=means[-1], cov=covs[-1], C=C[-1], Sigma=Sigma[-1], i=0, first=True)
+    assert abs(float(v) - float(g["lse_candidate"])) <= tol * abs(float(g["lse_candidate"]))
