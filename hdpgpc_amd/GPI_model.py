@@ -901,7 +901,12 @@ class GPI_model:
         Ms, Ss, means, scales = [C_], [Sig_], [self.C_def], [self.Sigma_def]
         if bool(torch.any(self.Gamma_def != 0)):
             Ms.append(A_), Ss.append(Gam_), means.append(self.A_def), scales.append(self.Gamma_def)
+        # the prior scales are the initial sigma I / gamma I unless a caller replaced them: checked once per pair of objects
+        key = (id(self.Sigma_def), id(self.Gamma_def))
+        if getattr(self, "_def_diag_key", None) != key:
+            self._def_diag = all(bool(torch.equal(s_, torch.diag(torch.diagonal(s_)))) for s_ in scales)
+            self._def_diag_key = key
         out, info = ops.mniw_loglik(torch.stack(Ms).contiguous(), torch.stack(Ss).contiguous(), torch.stack(means).contiguous(),
-                                    None, torch.stack(scales).contiguous())
+                                    None, torch.stack(scales).contiguous(), scale_is_diagonal=self._def_diag)
         ops.raise_on_info(info, "return_LDS_param_likelihood")
         return torch.sum(out) / T * 100.0

@@ -45,7 +45,7 @@ def _load():
         "hgp_gemm_batched_f64": (i32, [i32, i32, i32, i32, i32, f64, vp, i32, i64, vp, i32, i64, f64, vp, i32, i64, i32, vp]),
         "hgp_matrix_lik_ws_bytes": (sz, [i32, i32]),
         "hgp_lat_error_f64": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
-        "hgp_mniw_loglik_f64": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]),
+        "hgp_mniw_loglik_f64": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, sz, vp]),
         "hgp_warp_cov_f64": (i32, [vp, i32, f64, f64, f64, i32, vp, vp]),
         "hgp_chol_rank1_f64": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
         "hgp_trsv_lower_quad_f64": (i32, [vp, i32, vp, i32, vp, vp]),

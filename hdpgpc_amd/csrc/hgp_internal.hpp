@@ -72,4 +72,4 @@ size_t hgp_internal_acc_bytes(int TP, int K, size_t* sizes /*[6]*/);
 int hgp_internal_lat_error_wave(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* covprev,
                                 int T, int b, double* out, int32_t* info, hipStream_t st);
 int hgp_internal_mniw_wave(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov, const double* scale,
-                           long prior_stride, int T, int b, double* out, int32_t* info, hipStream_t st);
+                           int scale_is_diagonal, long prior_stride, int T, int b, double* out, int32_t* info, hipStream_t st);

@@ -2774,13 +2774,13 @@ int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A
 }
 
 int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov,
-                        const double* scale, long prior_stride, int T, int b, double* out, int32_t* info, void* ws,
-                        size_t ws_bytes, void* stream) {
+                        const double* scale, int scale_is_diagonal, long prior_stride, int T, int b, double* out, int32_t* info,
+                        void* ws, size_t ws_bytes, void* stream) {
   if (!M || !Sigma || !m_mean || !scale || !out || T <= 0 || b < 0) return -1;
   if (b == 0) return 0;
   if (T > HGP_MAX_T_COOP) return -2;
   if (T <= HGP_MAX_T_WAVE)   // fused: one wavefront per item, nothing goes through the workspace
-    return hgp_internal_mniw_wave(M, Sigma, m_mean, m_r_cov, scale, prior_stride, T, b, out, info, (hipStream_t)stream);
+    return hgp_internal_mniw_wave(M, Sigma, m_mean, m_r_cov, scale, scale_is_diagonal, prior_stride, T, b, out, info, (hipStream_t)stream);
   if (!ws || ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;   // 128 < T <= 256: composition of the batched kernels
   hipStream_t st = (hipStream_t)stream;
   const long tt = (long)T * T;

@@ -327,19 +327,23 @@ def lat_error(f_cur, f_prev, A, Gamma, covprev):
     return out, info
 
 
-def mniw_loglik(M, Sigma, m_mean, m_r_cov, scale):
-    """a9 batched.  M, Sigma [b,T,T]; prior (m_mean, scale, optional m_r_cov) [T,T] shared or [b,T,T] per item."""
+def mniw_loglik(M, Sigma, m_mean, m_r_cov, scale, scale_is_diagonal=None):
+    """a9 batched.  M, Sigma [b,T,T]; prior (m_mean, scale, optional m_r_cov) [T,T] shared or [b,T,T] per item.
+    scale_is_diagonal: None = check it here (one device comparison, host sync); callers that know (the hot path's
+    prior scale is sigma I) pass True / False."""
     M, Sigma = _dev64(M, "M"), _dev64(Sigma, "Sigma")
     b, T, _ = M.shape
     m_mean, scale = _dev64(m_mean, "m_mean"), _dev64(scale, "scale")
     stride = 0 if m_mean.dim() == 2 else T * T
+    if scale_is_diagonal is None:
+        scale_is_diagonal = bool(torch.equal(scale, torch.diag_embed(torch.diagonal(scale, dim1=-2, dim2=-1))))
     if m_r_cov is not None:
         m_r_cov = _dev64(m_r_cov, "m_r_cov")
     out = torch.empty(b, dtype=torch.float64, device=M.device)
     info = torch.zeros(b, dtype=torch.int32, device=M.device)
     nws = _ffi.lib.hgp_matrix_lik_ws_bytes(T, b) if T > 128 else 0     # T <= 128: one fused kernel, no workspace
     ws = torch.empty(nws, dtype=torch.uint8, device=M.device) if nws else None
-    _ffi.check(_ffi.lib.hgp_mniw_loglik_f64(_ptr(M), _ptr(Sigma), _ptr(m_mean), _ptr(m_r_cov), _ptr(scale), stride, T, b,
+    _ffi.check(_ffi.lib.hgp_mniw_loglik_f64(_ptr(M), _ptr(Sigma), _ptr(m_mean), _ptr(m_r_cov), _ptr(scale), int(scale_is_diagonal), stride, T, b,
                                             _ptr(out), _ptr(info), _ptr(ws), nws, _stream()), "mniw_loglik")
     return out, info
 

@@ -147,10 +147,11 @@ int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A
  *   L = chol(0.5 (Sigma + Sigma^T) + 1e-8 I);  D = M - m_mean
  *   out = -0.5 sum (D m_r_cov) o (Sigma^{-1} D) - 0.5 tr(Sigma^{-1} scale)
  * M, Sigma [b,T,T]; the prior (m_mean, m_r_cov, scale) is read with stride prior_stride (0 = shared by all items);
- * m_r_cov == NULL means the identity (the only value on the hot path, GPI_model.py:481-484). */
+ * m_r_cov == NULL means the identity (the only value on the hot path, GPI_model.py:481-484); scale_is_diagonal != 0 promises
+ * a diagonal `scale` (the prior's sigma I on the hot path): tr(Sigma^-1 scale) is then taken from the columns of L^-1 alone. */
 int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov,
-                        const double* scale, long prior_stride, int T, int b, double* out, int32_t* info, void* ws,
-                        size_t ws_bytes, void* stream);
+                        const double* scale, int scale_is_diagonal, long prior_stride, int T, int b, double* out, int32_t* info,
+                        void* ws, size_t ws_bytes, void* stream);
 
 /* a11 - WarpPriorAMTGP._rbf_cov (amtgp_warping_system.py:160-173): omega^2 exp(-0.5 dx^2/rho^2) + diag_add I on the
  * grid normalised to [0,1] when normalize != 0.  The batch score is then hgp_score_groups_f64 with jitter_rel = 0. */

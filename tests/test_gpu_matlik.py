@@ -44,7 +44,7 @@ def test_mniw_loglik_a9(T, b, prior):
     M = np.eye(T)[None] + 0.05 * rng.normal(size=(b, T, T))
     Sig = spd(rng, b, T, 0.7)
     if prior == "shared_identity":     # the hot path: prior = (C_def, I, Sigma_def) shared by all items (GPI_model.py:481-484)
-        mm, R, S = np.eye(T) * 0.9, None, np.eye(T) * 1.7
+        mm, R, S = np.eye(T) * 0.9, None, np.diag(rng.uniform(0.5, 3.0, T))
         out, info = ops.mniw_loglik(dev(M), dev(Sig), dev(mm), None, dev(S))
         ref = np.array([orc.mniw_log_likelihood(M[i], Sig[i], mm, np.eye(T), S) for i in range(b)])
     else:

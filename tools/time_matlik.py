@@ -37,6 +37,9 @@ for (b, T) in [(16384, 90), (2272, 90), (256, 90), (16, 90), (4096, 128), (8192,
     print(f"lat_error (a8)   b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} evals/s, {b*(3*T*T+2*T)*8/t/1e9:.0f} GB/s algorithmic", flush=True)
     M = dev(rng.normal(size=(b, T, T)))
     m0 = dev(np.eye(T))
+    sc = dev(1.7 * np.eye(T))          # the hot path's prior scale: sigma I (GPI_model.py:481-484)
+    t = timeit(lambda: ops.mniw_loglik(M, Gam, m0, None, sc, scale_is_diagonal=True), n=3, w=1)
+    print(f"mniw_loglik (a9) b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} evals/s, {b*2*T*T*8/t/1e9:.0f} GB/s algorithmic (diagonal prior scale)", flush=True)
     sc = dev(G[0])
-    t = timeit(lambda: ops.mniw_loglik(M, Gam, m0, None, sc), n=3, w=1)
-    print(f"mniw_loglik (a9) b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} evals/s, {b*2*T*T*8/t/1e9:.0f} GB/s algorithmic", flush=True)
+    t = timeit(lambda: ops.mniw_loglik(M, Gam, m0, None, sc, scale_is_diagonal=False), n=3, w=1)
+    print(f"mniw_loglik (a9) b={b} T={T}: {t*1e3:.3f} ms -> {b/t:.3e} evals/s (dense prior scale)", flush=True)
