@@ -585,6 +585,87 @@ class GPI_model:
         ops.lds_chain_finish(part, mm(e, e, transB=True), S__, i1, i2, ch["W"], n0, ch["Nf"], ch["bad"], ch["A"], ch["G"],
                              ch["C"], ch["S"], pos, self.annealing, ch["sync"], info0=i4)
 
+    def _chain_lists(self, ch):
+        """The member step as ONE launch per dependency level (hgp_chain.hip): every product of the step is an item of a
+        device-resident list whose pointers are fixed for the life of the chain; the two inversions carry their right-hand
+        sides.  14 launches per member, no torch arithmetic, no allocation (measured: a dependent launch costs ~4.5 us
+        whatever it does, so launches - not flops - were the step's time)."""
+        T = self.x_basis.shape[0]
+        tt = T * T
+        dev = self.device
+        new = lambda *shape: torch.zeros(shape, dtype=f64, device=dev)      # noqa: E731
+        ws = ch["ws"]
+        A, G, C, S, Psm, c0 = (ws[i * tt:(i + 1) * tt].view(T, T) for i in range(6))
+        m0, Fsm = ws[6 * tt:6 * tt + T], ws[6 * tt + T:]
+        X4, RH4, Z4, Y4 = new(4, T, T), new(4, T, T), new(4, T, T), new(4, T, T)    # [P, Sk, R0', R1'], their riding RHS, Z, Z rhs
+        S__, S_, Zs, Y3, part = new(2, T, T), new(2, T, T), new(2, T, T), new(2, T, T), new(2, T, T)
+        AP0, Pk, K_t, J, SINV, IKC, KS, MS, T1, KKt, KKtmP, c_post, CmP, X, P_sm_prev = (
+            new(T, T), new(T, T), new(T, T), new(T, T), new(2, T, T), new(T, T), new(T, T), new(2, T, T), new(T, T), new(T, T),
+            new(T, T), new(T, T), new(T, T), new(T, T), new(T, T))
+        y, xm, innov, f_post, w, f_sm_prev = new(T), new(T), new(T), new(T), new(T), new(T)
+        means = ch["W"][0]
+        P, Sk = X4[0], X4[1]
+        lv = [ops.GemmList(dev) for _ in range(10)]
+        # L1-L4: predictions (GPI.py:100-139; GPI.py:283-287 for the pair smoother's P = A c0 A^T + G)
+        lv[0].add(A, Psm, AP0)
+        lv[0].add(A, c0, RH4[0])                                  # A c0, the smoother gain's right-hand side
+        lv[0].add(A, Fsm, xm)
+        lv[1].add(AP0, A, Pk, D=G, transB=True)
+        lv[1].add(RH4[0], A, P, D=G, transB=True)
+        lv[1].add(C, xm, innov, D=y, alpha=-1.0)                  # y - C x_m
+        lv[2].add(C, Pk, RH4[1])                                  # C P_k, the Kalman gain's right-hand side
+        lv[3].add(RH4[1], C, Sk, D=S, transB=True)
+        # after INV1 (Z = L^-1 of P, Sk, R0', R1';  Y = Z rhs):  K = (C Pk)^T Sk^-1 = Y1^T Z1,  J = (A c0)^T P^-1 = Y0^T Z0
+        lv[4].add(Y4[1], Z4[1], K_t, transA=True)
+        lv[4].add(Y4[0], Z4[0], J, transA=True)
+        lv[4].add(Z4[2], Z4[2], SINV[0], transA=True)
+        lv[4].add(Z4[3], Z4[3], SINV[1], transA=True)
+        lv[5].add(K_t, innov, f_post, D=xm)
+        lv[5].add(K_t, C, IKC, alpha=-1.0, add_eye=1.0)
+        lv[5].add(K_t, S, KS)
+        lv[5].add(means[0], SINV[0], MS[0])
+        lv[5].add(means[1], SINV[1], MS[1])
+        lv[6].add(IKC, Pk, T1)
+        lv[6].add(KS, K_t, KKt, transB=True)
+        lv[6].add(KS, K_t, KKtmP, D=P, transB=True, beta=-1.0)
+        lv[6].add(A, m0, w, D=f_post, alpha=-1.0)                 # f_post - A m0
+        lv[7].add(T1, IKC, c_post, D=KKt, transB=True)            # Joseph form (GPI.py:148-150)
+        lv[7].add(T1, IKC, CmP, D=KKtmP, transB=True)             # c_post - P for the smoother
+        lv[7].add(J, w, f_sm_prev, D=m0)
+        lv[8].add(J, CmP, X)
+        lv[8].add(f_sm_prev, f_sm_prev, S__[0], D=SINV[0], transB=True)      # y2 y2^T + R'^-1 (GPI_model.py:1317-1322)
+        lv[8].add(f_post, f_post, S__[1], D=SINV[1], transB=True)
+        lv[8].add(f_post, f_sm_prev, S_[0], D=MS[0], transB=True)            # y1 y2^T + M R'^-1
+        lv[8].add(y, f_post, S_[1], D=MS[1], transB=True)
+        # after INV2 (Zs of S__ + 1e-8 I;  Y3 = Zs S_^T):  S_ S__^-1 = Y3^T Zs
+        lv[9].add(Y3[0], Zs[0], part[0], transA=True)
+        lv[9].add(Y3[1], Zs[1], part[1], transA=True)
+        lv[9].add(X, J, P_sm_prev, D=c0, transB=True)
+        for l_ in lv:
+            l_.finalize()
+        ch["lv"] = lv
+        ch["bufs"] = dict(X4=X4, RH4=RH4, Z4=Z4, Y4=Y4, S__=S__, S_=S_, Zs=Zs, Y3=Y3, part=part, y=y, f_post=f_post, c_post=c_post,
+                          f_sm_prev=f_sm_prev, P_sm_prev=P_sm_prev)
+        ch["rhs_on"] = torch.tensor([1, 1, 0, 0], dtype=torch.int32, device=dev)
+        ch["i4"] = torch.zeros(4, dtype=torch.int32, device=dev)
+        ch["i2"] = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    def _chain_step2(self, ch):
+        """_chain_step with one launch per dependency level; see _chain_lists."""
+        lv, b = ch["lv"], ch["bufs"]
+        ops.lds_chain_gather2(ch["A"], ch["G"], ch["C"], ch["S"], ch["Psm"], ch["P"], ch["F"], ch["Fsm"], ch["pos"], ch["ws"],
+                              ch["Y"], ch["y_row0"], b["y"], ch["W"], b["X4"][2:4])
+        for i in range(4):
+            lv[i].run()
+        ops.chol_inverse_rhs(b["X4"], b["Z4"], b["RH4"], b["Y4"], ch["i4"], rhs_on=ch["rhs_on"])
+        for i in range(4, 9):
+            lv[i].run()
+        ops.chol_inverse_rhs(b["S__"], b["Zs"], b["S_"], b["Y3"], ch["i2"], rhs_trans=True, add_diag=1e-8)
+        lv[9].run()
+        ops.lds_chain_finish2(b["f_post"], b["c_post"], b["f_sm_prev"], b["P_sm_prev"], b["y"], b["part"], b["S__"], ch["i4"], ch["i2"],
+                              ch["W"], ch["n0"], ch["Nf"], ch["bad"], ch["A"], ch["G"], ch["C"], ch["S"], ch["F"], ch["Fsm"], ch["P"],
+                              ch["Psm"], ch["pos"], self.annealing, ch["sync"])
+
     def _chain_commit(self, ch, members, x_trains, y_trains):
         L = int(ch["pos"][0]) + 1
         unb = lambda k: list(ch[k][:L].unbind(0))          # noqa: E731
@@ -601,10 +682,11 @@ class GPI_model:
         self.N += len(members)
         self._stk = {}
 
-    def _run_graphed(self, fn, n_iter):
-        """Run fn() n_iter times: once eagerly (warm-up, counts as the first iteration), then captured ONCE as a hipGraph and
-        replayed.  A failed capture or replay raises: silently re-running eagerly would both hide a 30x slow-down and, after
-        a partial replay, apply steps twice."""
+    def _run_graphed(self, fn, n_iter, unroll=1):
+        """Run fn() n_iter times: once eagerly (warm-up, counts as the first iteration), then `unroll` iterations captured ONCE
+        as a hipGraph and replayed (a replay costs ~8 us of launch gap, amortised over the unrolled iterations); the remainder
+        runs eagerly.  A failed capture or replay raises: silently re-running eagerly would both hide a 30x slow-down and,
+        after a partial replay, apply steps twice."""
         if n_iter <= 0:
             return
         self._check_pending()
@@ -616,17 +698,21 @@ class GPI_model:
         n_iter -= 1
         if n_iter == 0:
             return
+        unroll = max(1, min(int(unroll), n_iter))
         graph = torch.cuda.CUDAGraph()
         keep = self._pending
         try:
             with torch.cuda.graph(graph):
-                fn()
+                for _ in range(unroll):
+                    fn()
         except RuntimeError as e:
             raise RuntimeError(f"hipGraph capture of the LDS step failed: {e}") from e
         self._pending = keep + self._pending            # info tensors written by every replay
-        for _ in range(n_iter):
+        for _ in range(n_iter // unroll):
             graph.replay()
-        self.graph_replays = getattr(self, "graph_replays", 0) + n_iter
+        for _ in range(n_iter % unroll):
+            fn()
+        self.graph_replays = getattr(self, "graph_replays", 0) + n_iter // unroll
         self._graph_keepalive = graph
 
     def _backwards_graphed(self):
@@ -704,7 +790,11 @@ class GPI_model:
             # observations of the run; the step reads row (pos - y_row0) inside its gather kernel
             ch["Y"] = (y_trains[rest][..., 0] if y_trains.ndim == 3 else y_trains[rest]).reshape(len(rest), -1).contiguous()
             ch["y_row0"] = int(ch["pos"][0])
-            self._run_graphed(lambda: self._chain_step(ch), len(rest))
+            if self.x_basis.shape[0] <= 128 and not ops.env_flag("HGP_CHAIN_PER_PRODUCT"):
+                self._chain_lists(ch)
+                self._run_graphed(lambda: self._chain_step2(ch), len(rest), unroll=8)
+            else:                                       # T > 128: one launch per product (workgroup-cooperative inverses)
+                self._run_graphed(lambda: self._chain_step(ch), len(rest))
             self._chain_commit(ch, rest, x_trains, y_trains)
             bad = ch["bad"].tolist()
             if bad[1] != 0:      # torch.linalg.solve / inv of the reference would have raised at that member

@@ -53,6 +53,10 @@ def _load():
         "hgp_loglik_rows_f64": (i32, [vp, i32, i32, vp, vp, vp]),
         "hgp_assign_f64": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "hgp_warp_batch_f64": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp, vp, vp]),
+        "hgp_gemm_list_f64": (i32, [vp, i32, i32, vp]),
+        "hgp_chol_inverse_rhs_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, i32, vp, vp, vp]),
+        "hgp_lds_chain_gather2_f64": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, vp, vp, vp, vp]),
+        "hgp_lds_chain_finish2_f64": (i32, [i32] + [vp] * 22 + [i32, vp, vp]),
         "hgp_trsv_lower_solve_f64": (i32, [vp, i32, vp, i32, vp, vp, vp]),
         "hgp_lml_grad_f64": (i32, [vp, vp, vp, i32, f64, f64, f64, vp, vp]),
     }
@@ -64,6 +68,14 @@ def _load():
 
 
 lib, EXPORTS = _load()
+
+
+class GemmItem(ctypes.Structure):
+    """hgp_gemm_item of include/hdpgpc_hip.h."""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("D", ctypes.c_void_p), ("C", ctypes.c_void_p), ("C2", ctypes.c_void_p),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int),
+                ("ldc", ctypes.c_int), ("ldd", ctypes.c_int), ("tA", ctypes.c_int), ("tB", ctypes.c_int),
+                ("alpha", ctypes.c_double), ("beta", ctypes.c_double), ("add_eye", ctypes.c_double)]
 
 
 class HgpError(RuntimeError):

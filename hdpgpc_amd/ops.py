@@ -15,6 +15,11 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def env_flag(name):
+    import os
+    return os.environ.get(name, "0") not in ("", "0")
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -385,6 +390,97 @@ def lds_chain_finish(part, ee, Snew, info1, info2, W, n0, Nf, bad_count, stA, st
     _ffi.check(_ffi.lib.hgp_lds_chain_finish_f64(T, _ptr(part), _ptr(ee), _ptr(Snew), _ptr(info1), _ptr(info2), _ptr(info0), _ptr(W), _ptr(n0),
                                                  _ptr(Nf), _ptr(bad_count), _ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(pos),
                                                  int(bool(annealing)), _ptr(sync), _stream()), "lds_chain_finish")
+
+
+class GemmList:
+    """A device-resident list of products  C = alpha op(A) op(B) + beta D (+ add_eye I), run as ONE launch (hgp_gemm_list_f64).
+    Built once from tensors whose storage outlives the list; `add` takes tensors (2-D, or 1-D read as a column)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._items, self._keep, self.tiles = [], [], 0
+        self._dev = None
+
+    @staticmethod
+    def _dims(t):
+        if t.dim() == 1:
+            return t.shape[0], 1, 1
+        if t.stride(-1) != 1:
+            raise ValueError("gemm list operands must have unit inner stride")
+        return t.shape[0], t.shape[1], t.stride(0)
+
+    def add(self, A, B, out, D=None, transA=False, transB=False, alpha=1.0, beta=1.0, add_eye=0.0, out2=None):
+        ar, ac, lda = self._dims(A)
+        br, bc, ldb = self._dims(B)
+        M, K = (ac, ar) if transA else (ar, ac)
+        K2, N = (bc, br) if transB else (br, bc)
+        orow, ocol, ldc = self._dims(out)
+        if K != K2 or (orow, ocol) != (M, N) or max(M, N, K) > 128:
+            raise ValueError(f"gemm list item {M}x{K} . {K2}x{N} -> {orow}x{ocol}")
+        ldd = 0
+        if D is not None:
+            dr, dc, ldd = self._dims(D)
+            if (dr, dc) != (M, N):
+                raise ValueError("gemm list addend shape")
+        if out2 is not None and self._dims(out2) != (orow, ocol, ldc):
+            raise ValueError("gemm list second output must match the first")
+        for t in (A, B, out, D, out2):
+            if t is not None:
+                _dev64_any(t)
+                self._keep.append(t)
+        it = _ffi.GemmItem(A.data_ptr(), B.data_ptr(), D.data_ptr() if D is not None else None, out.data_ptr(),
+                           out2.data_ptr() if out2 is not None else None, M, N, K, lda, ldb, ldc, ldd, int(transA), int(transB),
+                           float(alpha), float(beta), float(add_eye))
+        self._items.append(it)
+        self.tiles += ((M + 15) // 16) * ((N + 15) // 16)
+        self._dev = None
+        return out
+
+    def finalize(self):
+        import numpy as np
+        arr = (_ffi.GemmItem * len(self._items))(*self._items)
+        host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+        self._dev = host.to(self.device)
+        return self
+
+    def run(self):
+        if self._dev is None:
+            self.finalize()
+        _ffi.check(_ffi.lib.hgp_gemm_list_f64(_ptr(self._dev), len(self._items), self.tiles, _stream()), "gemm_list")
+
+
+def _dev64_any(t):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float64):
+        raise TypeError("gemm list operands must be fp64 tensors on the GPU")
+
+
+def chol_inverse_rhs(A, Linv, rhs, rhs_out, info, rhs_on=None, rhs_trans=False, jitter_rel=0.0, add_diag=0.0):
+    """Z = chol(0.5 (A + A^T) + shift I)^{-1} -> Linv and Y = Z op(rhs) -> rhs_out from ONE factorisation per matrix of the batch
+    [b,T,T] (T <= 128), all outputs caller-allocated (capture-safe, no allocation)."""
+    A = _dev64(A, "A")
+    b, T, _ = A.shape
+    _ffi.check(_ffi.lib.hgp_chol_inverse_rhs_batched_f64(_ptr(A), T, b, float(jitter_rel), float(add_diag), _ptr(Linv), _ptr(rhs),
+                                                         _ptr(rhs_on), int(bool(rhs_trans)), _ptr(rhs_out), _ptr(info), _stream()),
+               "chol_inverse_rhs")
+
+
+def lds_chain_gather2(stA, stG, stC, stS, stPsm, stP, stF, stFsm, pos, out, Y, y_row0, y_out, W, Rp):
+    """lds_chain_gather + the jittered right covariances Rp = W[1] + 1e-2 mean|diag W[2]| I of the two MNIW updates."""
+    T = stA.shape[1]
+    _ffi.check(_ffi.lib.hgp_lds_chain_gather2_f64(_ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(stPsm), _ptr(stP), _ptr(stF),
+                                                  _ptr(stFsm), _ptr(pos), T, _ptr(out), _ptr(Y), int(y_row0), _ptr(y_out), _ptr(W),
+                                                  _ptr(Rp), _stream()), "lds_chain_gather2")
+
+
+def lds_chain_finish2(f_post, c_post, f_sm_prev, P_sm_prev, y, part, Snew, info1, info2, W, n0, Nf, bad_count, stA, stG, stC, stS, stF,
+                      stFsm, stP, stPsm, pos, annealing, sync):
+    """lds_chain_scatter + lds_chain_finish in one launch ((y1 - y2)(y1 - y2)^T formed inside)."""
+    T = stA.shape[1]
+    _ffi.check(_ffi.lib.hgp_lds_chain_finish2_f64(T, _ptr(f_post), _ptr(c_post), _ptr(f_sm_prev), _ptr(P_sm_prev), _ptr(y), _ptr(part),
+                                                  _ptr(Snew), _ptr(info1), _ptr(info2), _ptr(W), _ptr(n0), _ptr(Nf), _ptr(bad_count),
+                                                  _ptr(stA), _ptr(stG), _ptr(stC), _ptr(stS), _ptr(stF), _ptr(stFsm), _ptr(stP),
+                                                  _ptr(stPsm), _ptr(pos), int(bool(annealing)), _ptr(sync), _stream()),
+               "lds_chain_finish2")
 
 
 def trsv_lower_quad(G, y):

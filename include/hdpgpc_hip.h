@@ -205,6 +205,36 @@ int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const 
                              double* stA, double* stG, double* stC, double* stS, int64_t* pos, int annealing, int32_t* sync,
                              void* stream);
 
+/* 8f-1, one launch per dependency level of the member step.  hgp_gemm_list_f64 executes a DEVICE-resident list of
+ * heterogeneous products  C = alpha op(A) op(B) + beta D (+ add_eye on the diagonal), every dimension <= 128, vectors as N = 1;
+ * C2 (may be NULL) receives a second copy of the result.  total_tiles = sum over the items of ceil(M/16) ceil(N/16).
+ * A step's lists are built once (every pointer is fixed for the life of a chain) and replayed from a hipGraph. */
+typedef struct hgp_gemm_item {
+  const double* A;
+  const double* B;
+  const double* D;
+  double* C;
+  double* C2;
+  int M, N, K, lda, ldb, ldc, ldd, tA, tB;
+  double alpha, beta, add_eye;
+} hgp_gemm_item;
+int hgp_gemm_list_f64(const hgp_gemm_item* items_dev, int n_items, int total_tiles, void* stream);
+/* Cholesky inverse with the right-hand sides riding the factorisation (T <= 128): for every matrix of the batch
+ *   L = chol(0.5 (A + A^T) + shift I);  Linv = L^-1 (may be NULL);  rhs_out = L^-1 op(rhs)  (rhs NULL: none; rhs_on[m] == 0: not for m)
+ * so that  B^T A^-1 = rhs_out^T Linv  costs ONE product after the factorisation (GPI.py:144-145,295; GPI_model.py:1329-1330). */
+int hgp_chol_inverse_rhs_batched_f64(const double* A, int T, int b, double jitter_rel, double add_diag, double* Linv, const double* rhs,
+                                     const int32_t* rhs_on, int rhs_trans, double* rhs_out, int32_t* info, void* stream);
+/* hgp_lds_chain_gather_f64 plus the jittered right covariances of the two MNIW updates, Rp[2,T,T] = W[1] + 1e-2 max(mean|diag W[2]|, eps) I;
+ * hgp_lds_chain_scatter_f64 + hgp_lds_chain_finish_f64 in one launch, with (y1 - y2)(y1 - y2)^T formed inside; info1[4] = status of
+ * the first inversion (P, S_k, R0', R1'), info2[2] of the second. */
+int hgp_lds_chain_gather2_f64(const double* stA, const double* stG, const double* stC, const double* stS, const double* stPsm,
+                              const double* stP, const double* stF, const double* stFsm, const int64_t* pos, int T, double* out,
+                              const double* Y, long y_row0, double* y_out, const double* W, double* Rp, void* stream);
+int hgp_lds_chain_finish2_f64(int T, const double* f_post, const double* c_post, const double* f_sm_prev, const double* P_sm_prev,
+                              const double* y, const double* part, const double* Snew, const int32_t* info1, const int32_t* info2,
+                              double* W, double* n0, double* Nf, int32_t* bad_count, double* stA, double* stG, double* stC, double* stS,
+                              double* stF, double* stFsm, double* stP, double* stPsm, int64_t* pos, int annealing, int32_t* sync,
+                              void* stream);
 /* a10 helper - || G^{-1} y ||^2 for the lower triangle G of a [T, ld] matrix.  IterativeGaussianProcess.
  * log_marginal_likelihood as written passes K itself as the "factor" to cho_solve (GPI.py:1043); this reproduces
  * that call with G = tril(K).  out[1]. */
