@@ -23,5 +23,12 @@ $(LIB): $(OBJS)
 stamps: $(SRCS) $(HDR)
 	$(HIPCC) $(FLAGS) -DHGP_STAMPS -shared -o hdpgpc_amd/lib/libhdpgpc_hip_stamps.so $(SRCS)
 
+# diagnostic builds for the cooperative-factor race (tile_f64.hpp, coop_factor): a delay injected in front of the
+# right-hand-side row update, with the pre-round-2 round-robin dealing (races) and with the owner dealing (immune)
+raceprobe: $(SRCS) $(HDR)
+	mkdir -p build/probe
+	$(HIPCC) $(FLAGS) -DHGP_RACE_PROBE_DELAY -DHGP_RACE_PROBE_ROUNDROBIN -shared -o build/probe/libhgp_race_old.so $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
+	$(HIPCC) $(FLAGS) -DHGP_RACE_PROBE_DELAY -shared -o build/probe/libhgp_race_new.so $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
+
 clean:
 	rm -rf $(LIB) $(OBJDIR)

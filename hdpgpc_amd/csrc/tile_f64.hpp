@@ -768,11 +768,24 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
         ucur = unext;
       }
     }
-    if (RHS) {   // R_I -= U_KI^T Z_K for I > K, rows dealt to the waves round-robin
+    if (RHS) {   // R_I -= U_KI^T Z_K for I > K.  Row tile I belongs to the wave that OWNS block column I: that wave reads
+      // R_I at the top of step I (Z_I = W R_I) with no workgroup barrier in between, so nobody else may write it.
+      // (Until round 2 the rows were dealt round-robin, (I & 3) == wave, which differs from the snake ownership for
+      // columns 4-7 and 12-15: a write/read race across waves that ~4 k cycles of diag16 slack hid, and that a build
+      // slowed by register spills lost - the "wrong rows in L^-1" of DESIGN 7; `make raceprobe` + tools/probe_coop_race.py
+      // reproduce it with an injected delay.)
       const d4 zk = lds_tile_load(Rbuf, K, lane);
+#ifdef HGP_RACE_PROBE_DELAY
+      if (K + 1 < NB && ((K + 1) & 3) == wave && C::owner(K + 1) != wave)
+        for (int spin = 0; spin < 400; ++spin) __builtin_amdgcn_s_sleep(127);
+#endif
 #pragma unroll
       for (int I = K + 1; I < NB; ++I) {
+#ifdef HGP_RACE_PROBE_ROUNDROBIN
         if ((I & 3) == wave) {
+#else
+        if (C::owner(I) == wave) {
+#endif
           const d4 uki = lds_tile_load(rowbuf, I, lane);
           d4 ri = lds_tile_load(Rbuf, I, lane);
 #pragma unroll
