@@ -30,5 +30,10 @@ raceprobe: $(SRCS) $(HDR)
 	$(HIPCC) $(FLAGS) -DHGP_RACE_PROBE_DELAY -DHGP_RACE_PROBE_ROUNDROBIN -shared -o build/probe/libhgp_race_old.so $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
 	$(HIPCC) $(FLAGS) -DHGP_RACE_PROBE_DELAY -shared -o build/probe/libhgp_race_new.so $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
 
+# every workgroup barrier followed by a pseudo-random per-wave delay: run the GPU tests with HGP_LIB pointing at it
+racestress: $(SRCS) $(HDR)
+	mkdir -p build/probe
+	$(HIPCC) $(FLAGS) -DHGP_RACE_STRESS -shared -o build/probe/libhgp_race_stress.so $(SRCS)
+
 clean:
 	rm -rf $(LIB) $(OBJDIR)

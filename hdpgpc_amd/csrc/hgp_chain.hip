@@ -99,7 +99,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_inv_rhs(InvRhsArgs a) {
   const double* A = a.A + (size_t)m * T * T;
   d4 U[NB * (NB + 1) / 2];
   d4 R[NB];
-  load_sym_upper<NB>(U, A, T, T, lane, scr);
+  if constexpr (NB <= 6) load_sym_upper_burst<NB>(U, A, T, T, lane, scr);   // one exposed load latency instead of NB
+  else load_sym_upper<NB>(U, A, T, T, lane, scr);
   {
     double sh = a.add;
     if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(diag_abs_mean<NB>(U, T, lane, a.add), F64_EPS);

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_inv(PotrfArgs a) {
   d4 U[NB * (NB + 1) / 2];
   d4 R[NB];
   if (a.symmetric) load_upper_only<NB>(U, A, T, T, lane);
+  else if constexpr (NB <= 6) load_sym_upper_burst<NB>(U, A, T, T, lane, scr);   // latency-bound: all loads in flight at once
   else load_sym_upper<NB>(U, A, T, T, lane, scr);
   {
     double sh = a.add;

@@ -37,6 +37,20 @@ constexpr int DIAG_SCR = 16 * DIAG_LD;   // doubles of LDS scratch each wave nee
 constexpr double F64_EPS = 2.220446049250313e-16;
 
 __host__ __device__ constexpr int tix(int I, int J, int NB) { return I * NB - (I * (I - 1)) / 2 + (J - I); }
+#ifdef HGP_RACE_STRESS
+// Diagnostic build (`make racestress`): after every workgroup barrier each wave sleeps a pseudo-random, wave-dependent 0-25 k
+// cycles - more than any latency that could hide a missing barrier.  The GPU test-suite run against this build
+// (HGP_LIB=build/probe/libhgp_race_stress.so) is the race check of every cooperative kernel.
+__device__ __forceinline__ void hgp_sync_stress() {
+  __syncthreads();
+  const unsigned w = threadIdx.x >> 6;
+  const unsigned h = ((w + 1u) * 2654435761u) ^ (unsigned)(__builtin_readcyclecounter() >> 9);
+  const unsigned n = __builtin_amdgcn_readfirstlane(((h >> 3) & 3u) * 4u);
+  for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+}
+#define __syncthreads() ::hgp::hgp_sync_stress()
+#endif
+
 __host__ __device__ constexpr int ntiles(int NB) { return NB * (NB + 1) / 2; }
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
@@ -467,6 +481,57 @@ __device__ __forceinline__ void load_sym_upper(d4 (&U)[NB * (NB + 1) / 2], const
         const int i = 16 * I + g + 4 * r, j = 16 * J + c;
         const double t = scr[c * DIAG_LD + g + 4 * r];               // element (c, g + 4r) of src = A[j][i]
         double x = 0.5 * (nat[J][r] + t);
+        if (!(i < n && j < n)) x = (i == j) ? 1.0 : 0.0;
+        v[r] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
+      U[tix(I, J, NB)] = v;
+    }
+  }
+}
+
+// load_sym_upper with ALL global loads in flight at once (the upper tiles land in U, the NB (NB - 1) / 2 transposed partners
+// in temporaries: 36 tiles = 288 VGPRs at NB = 6), then the LDS transposes: ONE exposed load latency instead of NB.
+// For the latency-bound one-wave-per-SIMD kernels at NB <= 6.  Same result as load_sym_upper, bit for bit.
+template <int NB>
+__device__ __forceinline__ void load_sym_upper_burst(d4 (&U)[NB * (NB + 1) / 2], const double* __restrict__ A, int ld, int n,
+                                                     int lane_in, double* scr) {
+  constexpr int NO = NB > 1 ? NB * (NB - 1) / 2 : 1;
+  d4 trn[NO];
+  {
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + g + 4 * r, j = 16 * J + c;          // natural element of tile (I, J)
+          U[tix(I, J, NB)][r] = (i < n && j < n) ? A[(size_t)i * ld + j] : 0.0;
+          if (J > I) {
+            const int i2 = 16 * J + g + 4 * r, j2 = 16 * I + c;      // natural element of tile (J, I)
+            trn[tix(I, J, NB) - (I + 1)][r] = (i2 < n && j2 < n) ? A[(size_t)i2 * ld + j2] : 0.0;
+          }
+        }
+  }
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+#pragma unroll
+    for (int J = I; J < NB; ++J) {
+      const int lane = launder(lane_in);
+      const int g = lane >> 4, c = lane & 15;
+      const d4 nat = U[tix(I, J, NB)];
+      const d4 src = (J == I) ? nat : trn[(J == I) ? 0 : tix(I, J, NB) - (I + 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scr[(g + 4 * r) * DIAG_LD + c] = src[r];
+      __builtin_amdgcn_wave_barrier();
+      d4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;
+        const double t = scr[c * DIAG_LD + g + 4 * r];               // element (c, g + 4r) of src = A[j][i]
+        double x = 0.5 * (nat[r] + t);
         if (!(i < n && j < n)) x = (i == j) ? 1.0 : 0.0;
         v[r] = x;
       }
