@@ -156,6 +156,41 @@ def secondary_rank1(dev, ops, b=1024, T=256, reps=5):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
 
 
+def secondary_matrix_terms(dev, ops, b=16384, T=90, reps=5):
+    """a8 (latent-transition score) and a9 (MNIW log-likelihood of the LDS parameters, the online hot spot) at the
+    records' size T = 90: one fused kernel each, one wavefront per item.  Algorithmic HBM bytes per item:
+    a8 3 T^2 + 2 T doubles (A, Gamma, P, two vectors), a9 2 T^2 (M, Sigma; the prior is shared)."""
+    rng = np.random.default_rng(3)
+    Q = rng.normal(size=(8, T, T))
+    G = Q @ Q.transpose(0, 2, 1) / T + np.eye(T)
+    d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
+    Gam = d(np.tile(G, (b // 8, 1, 1)))
+    A = d(rng.normal(size=(b, T, T)) * 0.1)
+    fc, fp = d(rng.normal(size=(b, T))), d(rng.normal(size=(b, T)))
+    M, m0, sc = d(rng.normal(size=(b, T, T))), d(np.eye(T)), d(1.7 * np.eye(T))
+
+    def timed(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out[0] if isinstance(out, tuple) else out).all())
+        return e0.elapsed_time(e1) / reps
+
+    ms8 = timed(lambda: ops.lat_error(fc, fp, A, Gam, Gam))
+    ms9 = timed(lambda: ops.mniw_loglik(M, Gam, m0, None, sc, scale_is_diagonal=True))
+    gb8 = b * (3.0 * T * T + 2 * T) * 8 / (ms8 * 1e-3) / 1e9
+    gb9 = b * 2.0 * T * T * 8 / (ms9 * 1e-3) / 1e9
+    return {"workload": f"{b} items, T={T}: a8 hgp_lat_error_f64 (k_wave_lat_gram), a9 hgp_mniw_loglik_f64 (k_wave_mniw, diagonal prior scale)",
+            "a8": {"value": b / (ms8 * 1e-3), "unit": "evals/s", "kernel_ms": ms8,
+                   "roofline": {"bound": "hbm", "achieved": gb8, "peak": 8000.0, "unit": "GB/s", "frac": gb8 / 8000.0}},
+            "a9": {"value": b / (ms9 * 1e-3), "unit": "evals/s", "kernel_ms": ms9,
+                   "roofline": {"bound": "hbm", "achieved": gb9, "peak": 8000.0, "unit": "GB/s", "frac": gb9 / 8000.0}}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,6 +302,7 @@ def main():
             res["secondary"] = secondary_shared_grid(dev, ops)
             res["secondary_large_T"] = secondary_large_T(dev, ops, synth)
             res["secondary_rank1"] = secondary_rank1(dev, ops)
+            res["secondary_matrix_terms"] = secondary_matrix_terms(dev, ops)
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)

@@ -832,6 +832,20 @@ class GPI_model:
         ops.raise_on_info(info, "_gaussian_score_shared_cov")
         return -0.5 * quad - 0.5 * T * LOG2PI
 
+    def _pairs_plan(self, Ts, K):
+        """Per-pair plans (device buffer + handle) are kept per (segment length, cluster count, theta): the online loop calls
+        log_sq_error 1 + 2M times per beat on irregular grids; only update() (the per-cluster operators) runs per call."""
+        theta = tuple(float(v) for v in self.gp.kernel.params())
+        cache = self.__dict__.setdefault("_plans", {})
+        key = (int(Ts), int(K), theta)
+        plan = cache.get(key)
+        if plan is None:
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            plan = ops.PairsPlan(self.x_basis.shape[0], int(Ts), np.repeat(np.asarray(theta)[None], int(K), 0), device=self.device)
+            cache[key] = plan
+        return plan
+
     # ------------------------------------------------------------------ a5
     def log_sq_error(self, x_train, y, mean=None, cov=None, C=None, Sigma=None, i=None, proj=False, first=False):
         """GPI_model.py:250-286: score of ONE segment (no log-determinant)."""
@@ -853,7 +867,7 @@ class GPI_model:
             items = ops.build_items([0], [fn], [1])
             quad, _, info = ops.score_groups(y, m.reshape(1, T).contiguous(), S.reshape(1, T, T).contiguous(), *items)
         else:
-            plan = ops.PairsPlan(T, x.shape[0], [self.gp.kernel.params()], device=self.device)
+            plan = self._pairs_plan(x.shape[0], 1)
             plan.update(self.x_basis.reshape(-1).contiguous(), m.reshape(1, T).contiguous(), S.reshape(1, T, T).contiguous())
             ops.raise_on_info(plan.info, "pred_dist")
             fnt = torch.full((1, 1), fn, dtype=f64, device=self.device) if first else None
@@ -931,7 +945,7 @@ class GPI_model:
         means = ops.gemm_batched(self._S("C")[torch.as_tensor(pairs[:, 0], device=self.device)],
                                  self._S("f_star")[torch.as_tensor(pairs[:, 1], device=self.device)]).reshape(-1, T)
         Sig = self._S("Sigma")[torch.as_tensor(pairs[:, 0], device=self.device)].contiguous()
-        plan = ops.PairsPlan(T, Ts, np.repeat(np.asarray(self.gp.kernel.params())[None], len(pairs), 0), device=self.device)
+        plan = self._pairs_plan(Ts, len(pairs))
         plan.update(self.x_basis.reshape(-1).contiguous(), means.contiguous(), Sig)
         ops.raise_on_info(plan.info, "pred_dist")
         fn = torch.as_tensor(np.where(first, ini_noise, 0.0), dtype=f64, device=self.device)

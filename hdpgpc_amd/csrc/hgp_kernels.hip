@@ -439,14 +439,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_inv(PotrfArgs a) {
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once for every (kernel, device)
+// this process launches on, under a lock (the launchers are called from any host thread).
+static int ensure_dynamic_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dv = 0;
+  if (hipGetDevice(&dv) != hipSuccess) return launch_status();
+  std::lock_guard<std::mutex> lk(mu);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == dv) return 0;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return 1000 + (int)e;
+  done.emplace_back(fn, dv);
+  return 0;
+}
+
 template <int NB>
 int launch_coop_score(const ScoreArgs& a, hipStream_t st) {
   const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coop_score<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_score<NB>), lds)) return rc_;
   hipLaunchKernelGGL(k_coop_score<NB>, dim3(a.n_items), dim3(64 * WAVES), lds, st, a);
   return launch_status();
 }
@@ -454,12 +466,8 @@ int launch_coop_score(const ScoreArgs& a, hipStream_t st) {
 template <int NB>
 int launch_coop_potrf(const PotrfArgs& a, hipStream_t st) {
   const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coop_potrf<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coop_inv<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_potrf<NB>), lds)) return rc_;
+  if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_inv<NB>), lds)) return rc_;
   if (a.Linv) hipLaunchKernelGGL(k_coop_inv<NB>, dim3(a.b, NB), dim3(64 * WAVES), lds, st, a);
   hipLaunchKernelGGL(k_coop_potrf<NB>, dim3(a.b), dim3(64 * WAVES), lds, st, a);
   return launch_status();
@@ -2421,11 +2429,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
 template <int NB>
 int launch_pairs_cooph(const PairsArgs& a, hipStream_t st) {
   const size_t lds = PairsCoop<NB>::LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs_cooph<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs_cooph<NB>), lds)) return rc_;
   const int blocks = a.sel ? a.N : a.N * (a.kend - a.kbeg);
   hipLaunchKernelGGL(k_pairs_cooph<NB>, dim3(blocks), dim3(64 * CoopH<NB>::NW), lds, st, a);
   return launch_status();
@@ -2434,11 +2438,7 @@ int launch_pairs_cooph(const PairsArgs& a, hipStream_t st) {
 template <int NB>
 int launch_pairs_coop(const PairsArgs& a, hipStream_t st) {
   const size_t lds = PairsCoop<NB>::LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs_coop<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs_coop<NB>), lds)) return rc_;
   const int blocks = a.sel ? a.N : a.N * (a.kend - a.kbeg);
   hipLaunchKernelGGL(k_pairs_coop<NB>, dim3(blocks), dim3(64 * WAVES), lds, st, a);
   return launch_status();
@@ -2447,11 +2447,7 @@ int launch_pairs_coop(const PairsArgs& a, hipStream_t st) {
 template <int NB>
 int launch_pairs(const PairsArgs& a, hipStream_t st) {
   size_t lds = pairs_lds_bytes<NB>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairs<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs<NB>), lds)) return rc_;
   hipLaunchKernelGGL(k_pairs<NB>, dim3(a.N), dim3(64 * WAVES), lds, st, a);
   return launch_status();
 }
@@ -2703,6 +2699,11 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
   if (Ts > p->TP) return -2;   // plan was created with a smaller Ts_max
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
+  // the hand-out flags of the overflow areas start every call at "free": a launch that was killed mid-flight cannot leave the
+  // next one spinning (a plan serves ONE stream at a time; see the header)
+  if (p->coop && p->d_eflags && p->nscr > 0 &&
+      hipMemsetAsync(p->d_eflags, 0, (p->nscr + 1) * sizeof(int32_t), st) != hipSuccess)
+    return launch_status();
   for (size_t gi = 0; gi < p->grp_beg.size() && rc == 0; ++gi) {
     PairsArgs a{x, y, N, Ts, p->d_xb, p->T, p->d_Mp, p->d_ap, p->d_scal, p->d_perm, p->grp_beg[gi], p->grp_end[gi],
                 p->grp_ell[gi], first_noise, sel,
@@ -2870,18 +2871,7 @@ int hgp_rts_chain_f64(const double* J, const double* P, const double* AM, double
   if (n < 2) return 0;
   RtsArgs a{J, P, AM, M, Cv, n, T};
   const size_t lds = sizeof(double) * (2 * 96 * 100 + 96);
-  {   // the attribute is per device: set it once for each device this process launches on
-    static std::mutex mu;
-    static bool done[64] = {false};
-    int dv = 0;
-    if (hipGetDevice(&dv) != hipSuccess) return launch_status();
-    std::lock_guard<std::mutex> lk(mu);
-    if (dv < 0 || dv >= 64 || !done[dv]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rts_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return 1000 + (int)e;
-      if (dv >= 0 && dv < 64) done[dv] = true;
-    }
-  }
+  if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_rts_chain), lds)) return rc_;
   hipLaunchKernelGGL(k_rts_chain, dim3(1), dim3(64 * RTS_WAVES), lds, (hipStream_t)stream, a);
   return launch_status();
 }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HGP_ABI_VERSION 3   /* 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path) */
+#define HGP_ABI_VERSION 3   /* 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path), assignment tail, warp fit, member-step lists */
 /* largest T (basis length) and T* (segment length) served by the register-resident wave kernels */
 #define HGP_MAX_T_WAVE 128
 /* largest T served at all: 128 < T <= 256 runs on cooperative kernels (one workgroup of 4-8 waves per matrix / pair) */
@@ -108,7 +108,9 @@ int hgp_pairs_plan_update(hgp_pairs_plan* plan, const double* x_basis, const dou
  * (Sigma iso-diagonal, GPI.py:497), mean(diag Sigma), jitter of K~, kinv = ||K~^{-1}||_inf, 0.
  * The per-pair kernel evaluates cov_f through the explicit operator M; its rounding error relative to the
  * reference's triangular solves grows like eps * (c * kinv)^2 (about 1e-10 for the reference's length-scale
- * 1.2 on a unit-spaced grid, where parity is 1e-11; quickly worse for smoother kernels) - callers check it. */
+ * 1.2 on a unit-spaced grid, where parity is 1e-11; quickly worse for smoother kernels); hgp_pairs_plan_update compares it
+ * with the tolerance of hgp_pairs_plan_set_accuracy ON THE DEVICE and routes such clusters to the solve-based kernel
+ * (scalar 7 = the flag): no caller has to check anything. */
 const double* hgp_pairs_plan_scalars(const hgp_pairs_plan* plan);
 /* Which clusters take the solve-based evaluation (the reference's operation order, GPI.py:489-501: S = cholesky_solve(K*, L)
  * by blocked substitution per pair, cov_f = K** + S^T (Sigma S - K*)) instead of the explicit operator M:
@@ -121,7 +123,9 @@ int hgp_pairs_plan_set_accuracy(hgp_pairs_plan* plan, double tol);
  * out_info (may be NULL).  cov carries the reference's regularisation: +1e-6 I (GPI.py:501, dense Sigma only),
  * + first_noise, + 1e-8 mean|diag| I (GPI_model.py:83-87). */
 /* sel[N] (may be NULL): segment n is scored against cluster sel[n] only - the per-segment LDS step of
- * GPI_model.compute_sq_err_all's irregular-grid loop (GPI_model.py:535-545); outputs and first_noise are then [N]. */
+ * GPI_model.compute_sq_err_all's irregular-grid loop (GPI_model.py:535-545); outputs and first_noise are then [N].
+ * A plan serves one stream at a time (its workspace and, for Ts > 128, the overflow areas handed out inside the kernel belong to
+ * the call; the hand-out flags are reset at the start of every call). */
 int hgp_loglik_pairs_f64(const hgp_pairs_plan* plan, const double* x, const double* y, int N, int Ts,
                          const double* first_noise, const int32_t* sel, double* out_quad, double* out_logdet,
                          int32_t* out_info, void* stream);
