@@ -190,6 +190,37 @@ def test_producer_full_pass_weighted_reproduces_reference_state(tag, members):
     assert rel_err(q_lat.cpu().numpy()[members], g["q_lat"][members]) < 1e-6
 
 
+def test_producer_step_forms_agree(monkeypatch):
+    """The member step exists in three forms - one launch per dependency level (hgp_chain.hip, the default for T <= 128), one
+    launch per product (128 < T <= 256; HGP_CHAIN_PER_PRODUCT=1 forces it) and the eager methods (use_graphs=False).  They
+    order the same arithmetic differently (B^T A^-1 as (Z B)^T Z against B^T (Z^T Z)): every list must agree to 1e-9."""
+    g = golden("state_t45.npz")
+    y = g["y"]
+    n, T = y.shape
+    members = [int(v) for v in g["st_indexes"]]
+    sigma, gamma = float(g["st_Sigma"][0][0, 0]), float(g["st_Gamma"][0][0, 0])
+    xs = np.repeat(g["st_x_basis"][None, :, None], n, axis=0)
+    resp = np.zeros(n)
+    resp[members] = 1.0
+    states = []
+    for form in ("levels", "products", "eager"):
+        if form == "products":
+            monkeypatch.setenv("HGP_CHAIN_PER_PRODUCT", "1")
+        else:
+            monkeypatch.delenv("HGP_CHAIN_PER_PRODUCT", raising=False)
+        m = GPI_model(RBFWhiteKernel(300.0, 3.0, sigma * 1e-5), g["st_x_basis"][:, None], annealing=True, bayesian=True, free_deg_MNIV=5)
+        cond = m.GPR_dynamic(gamma, sigma)
+        m.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
+        m.fixed_theta = tuple(float(v) for v in g["st_theta"])
+        q, q_lat = m.full_pass_weighted(xs, y[:, :, None], resp, use_graphs=(form != "eager"))
+        assert (getattr(m, "graph_replays", 0) > 0) == (form != "eager")
+        states.append({k: torch.stack(getattr(m, k)).cpu().numpy() for k in ("f_star", "f_star_sm", "cov_f", "cov_f_sm", "A", "Gamma", "C", "Sigma")}
+                      | {"q": q.cpu().numpy(), "q_lat": q_lat.cpu().numpy()[members], "n0": np.asarray(float(m.internal_params.n0))})
+    for other in states[1:]:
+        for k, ref in states[0].items():
+            assert np.allclose(other[k], ref, rtol=1e-9, atol=1e-9 * max(np.abs(ref).max(), 1e-300)), k
+
+
 def test_soft_members_are_skipped_like_the_reference():
     """A responsibility in (0.99, 1) (e.g. 0.9999 from the variational step) makes a segment 'active' but h != 1: the
     reference then skips it entirely - include_sample(posterior=False), backwards_pair and bayesian_new_params are no-ops
