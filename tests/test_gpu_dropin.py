@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, rel_err
+from conftest import golden, rel_err, relclose
 
 pytestmark = pytest.mark.gpu
 
@@ -43,15 +43,15 @@ def test_reload_from_labels_and_classify_record_102():
     assert np.array_equal(sw_gp.resp_assigned[-1].numpy(), g["resp_assigned"])
     # the HDP pseudo-counts cluster_new_batch reads (host side; surrogate bound optimised as in the reference)
     assert np.allclose(sw_gp.transTheta, g["transTheta"], rtol=1e-8) and np.allclose(sw_gp.startTheta, g["startTheta"], rtol=1e-8)
-    assert np.allclose(sw_gp.rho, g["rho"], rtol=1e-7) and np.allclose(sw_gp.omega, g["omega"], rtol=1e-7)
+    assert np.allclose(sw_gp.rho, g["rho"], rtol=1e-9) and np.allclose(sw_gp.omega, g["omega"], rtol=1e-9)
     # the score matrices of the rebuilt models: 2 187 Kalman / MNIW steps per lead, then a6 / a8
-    assert rel_err(sw_gp.q_last[:, :, 0].cpu().numpy(), g["q_last"]) < 1e-5
+    assert rel_err(sw_gp.q_last[:, :, 0].cpu().numpy(), g["q_last"]) < 1e-7
     members = g["q_lat_last"] != 0.0
-    assert rel_err(sw_gp.q_lat_last[:, :, 0].cpu().numpy()[members], g["q_lat_last"][members]) < 1e-5
+    assert rel_err(sw_gp.q_lat_last[:, :, 0].cpu().numpy()[members], g["q_lat_last"][members]) < 1e-7
     # classification of the batch with the frozen models: the N x M score matrix and the label tensor
     xt, yt = sw_gp.cond_to_torch(x_trains), sw_gp.cond_to_torch(data)
     q_new = sw_gp.frozen_scores(xt, yt)[:, :, 0].cpu().numpy()
-    assert rel_err(q_new, g["q_new"]) < 1e-6
+    assert rel_err(q_new, g["q_new"]) < 1e-7
     new_labels = sw_gp.cluster_new_batch(x_trains, data)
     assert new_labels.dtype == torch.int64
     assert np.array_equal(new_labels.numpy(), g["new_labels"])           # bit-identical assignments

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, rel_err
+from conftest import golden, rel_err, relclose
 from oracle import hdpgpc_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -65,8 +65,8 @@ def test_gpi_model_scoring_half(tag):
     assert abs(float(v) - float(g["mniw_obs"])) <= RT * abs(float(g["mniw_obs"]))
     # a7 + a2: observe_last on the dense plotting grid (T* = 2T-1 > T)
     f, cov = m.observe_last(g["x_dense"][:, None])
-    assert np.allclose(f.cpu().numpy()[:, 0], g["obs_last_f"], rtol=1e-7, atol=1e-7 * np.abs(g["obs_last_f"]).max())
-    assert np.allclose(cov.cpu().numpy(), g["obs_last_cov"], rtol=1e-7, atol=1e-7 * np.abs(g["obs_last_cov"]).max())
+    assert relclose(f.cpu().numpy()[:, 0], g["obs_last_f"], 1e-9)
+    assert relclose(cov.cpu().numpy(), g["obs_last_cov"], 1e-9)
 
 
 def test_pred_dist_and_latent_golden():
@@ -75,11 +75,11 @@ def test_pred_dist_and_latent_golden():
         c, ell, noise = (float(v) for v in g[f"c{i}_theta"])
         gp = IterativeGaussianProcess(RBFWhiteKernel(c, ell, noise), g[f"c{i}_xb"][:, None])
         f, cov = gp.pred_dist(g[f"c{i}_xp"][:, None], g[f"c{i}_xb"][:, None], g[f"c{i}_mean"][:, None], g[f"c{i}_Sigma"])
-        assert np.allclose(f.cpu().numpy()[:, 0], g[f"c{i}_f"], rtol=1e-7, atol=1e-7 * np.abs(g[f"c{i}_f"]).max())
-        assert np.allclose(cov.cpu().numpy(), g[f"c{i}_cov"], rtol=1e-7, atol=1e-7 * np.abs(g[f"c{i}_cov"]).max())
+        assert relclose(f.cpu().numpy()[:, 0], g[f"c{i}_f"], 1e-7)
+        assert relclose(cov.cpu().numpy(), g[f"c{i}_cov"], 1e-7)
         fl, covl = gp.pred_latent_dist(g[f"c{i}_xp"][:, None], g[f"c{i}_xb"][:, None], g[f"c{i}_mean"][:, None], g[f"c{i}_Sigma"])
-        assert np.allclose(fl.cpu().numpy()[:, 0], g[f"c{i}_f_lat"], rtol=1e-6, atol=1e-6 * np.abs(g[f"c{i}_f_lat"]).max())
-        assert np.allclose(covl.cpu().numpy(), g[f"c{i}_cov_lat"], rtol=1e-6, atol=1e-6 * np.abs(g[f"c{i}_cov_lat"]).max())
+        assert relclose(fl.cpu().numpy()[:, 0], g[f"c{i}_f_lat"], 1e-7)
+        assert relclose(covl.cpu().numpy(), g[f"c{i}_cov_lat"], 1e-7)
 
 
 def test_lml_a10_golden():
@@ -176,18 +176,18 @@ def test_producer_full_pass_weighted_reproduces_reference_state(tag, members):
     resp[members] = 1.0
     q, q_lat = m.full_pass_weighted(xs, y[:, :, None], resp)
     assert m.indexes == members
-    tol = 1e-7
+    tol = 1e-9      # SURVEY section 7's gate; observed 1e-10 (gpurun_out/parity_observed.json)
     for name in ("f_star", "f_star_sm"):
         got = torch.stack(getattr(m, name)).cpu().numpy()[:, :, 0]
-        assert np.allclose(got, g["st_" + name], rtol=tol, atol=tol * np.abs(g["st_" + name]).max()), name
+        assert relclose(got, g["st_" + name], tol), name
     for name in ("cov_f_sm", "A", "Gamma", "C", "Sigma"):
         got = torch.stack(getattr(m, name)).cpu().numpy()
         ref = g["st_" + name]
         assert got.shape == ref.shape, name
-        assert np.allclose(got, ref, rtol=tol, atol=tol * np.abs(ref).max()), name
+        assert relclose(got, ref, tol), name
     assert float(m.internal_params.n0) == float(g["st_n0"])
-    assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-6
-    assert rel_err(q_lat.cpu().numpy()[members], g["q_lat"][members]) < 1e-6
+    assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-9
+    assert rel_err(q_lat.cpu().numpy()[members], g["q_lat"][members]) < 1e-9
 
 
 def test_producer_step_forms_agree(monkeypatch):
@@ -243,11 +243,11 @@ def test_soft_members_are_skipped_like_the_reference():
         assert m.indexes == members
         for name in ("f_star", "f_star_sm"):
             got = torch.stack(getattr(m, name)).cpu().numpy()[:, :, 0]
-            assert np.allclose(got, g["st_" + name], rtol=1e-7, atol=1e-7 * np.abs(g["st_" + name]).max()), name
+            assert relclose(got, g["st_" + name], 1e-9), name
         for name in ("A", "Gamma", "C", "Sigma"):
             got = torch.stack(getattr(m, name)).cpu().numpy()
-            assert np.allclose(got, g["st_" + name], rtol=1e-7, atol=1e-7 * np.abs(g["st_" + name]).max()), name
-        assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-6
+            assert relclose(got, g["st_" + name], 1e-9), name
+        assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-9
 
 
 def test_pending_info_names_the_failing_step():
@@ -280,10 +280,10 @@ def test_online_side_producer_pieces():
     resp = np.zeros(n)
     resp[members] = 1.0
     m.full_pass_weighted(xs, y[:, :, None], resp)
-    tol = 1e-6
+    tol = 1e-9
 
     def close(a, b):
-        return np.allclose(a, b, rtol=tol, atol=tol * np.abs(b).max())
+        return relclose(a, b, tol)
 
     for tag, xx in (("shared", xs[21]), ("irr", e["x_irr"][:, None])):
         for h in (1.0, 0.6):
@@ -303,8 +303,8 @@ def test_online_side_producer_pieces():
     resp = np.zeros(n)
     resp[[5, 6, 9, 10, 12]] = 1.0
     q2, ql2 = m.full_pass_weighted(xs, y[:, :, None], resp)
-    assert rel_err(q2.cpu().numpy(), e["re_q"]) < 1e-6
-    assert rel_err(ql2.cpu().numpy()[[5, 6, 9, 10, 12]], e["re_q_lat"][[5, 6, 9, 10, 12]]) < 1e-6
+    assert rel_err(q2.cpu().numpy(), e["re_q"]) < 1e-9
+    assert rel_err(ql2.cpu().numpy()[[5, 6, 9, 10, 12]], e["re_q_lat"][[5, 6, 9, 10, 12]]) < 1e-9
     assert close(m.Sigma[-1].cpu().numpy(), e["re_Sigma_last"]) and close(m.f_star_sm[-1].cpu().numpy()[:, 0], e["re_f_sm_last"])
 
 
@@ -329,13 +329,13 @@ def test_replay_offline_trace_from_labels():
         qm, qlat = mod.full_pass_weighted(xs, y[:, :, None], resp)
         S = len(mod.f_star)
         means = np.stack([(mod.C[min(i, len(mod.C) - 1)] @ mod.f_star[i]).cpu().numpy().reshape(-1) for i in range(S)])
-        assert np.allclose(means, g[f"m{mi}_means"], rtol=1e-6, atol=1e-6 * np.abs(g[f"m{mi}_means"]).max())
+        assert relclose(means, g[f"m{mi}_means"], 1e-9)
         Sg = torch.stack(mod.Sigma).cpu().numpy()
-        assert np.allclose(Sg, g[f"m{mi}_Sigma"], rtol=1e-6, atol=1e-6 * np.abs(g[f"m{mi}_Sigma"]).max())
+        assert relclose(Sg, g[f"m{mi}_Sigma"], 1e-9)
         assert float(mod.internal_params.n0) == float(g[f"m{mi}_n0"])
-        assert rel_err(qlat.cpu().numpy()[members], g[f"m{mi}_q_lat"][members]) < 1e-5
+        assert rel_err(qlat.cpu().numpy()[members], g[f"m{mi}_q_lat"][members]) < 1e-9
         q[:, mi] = qm.cpu().numpy()
-    assert rel_err(q, g["q"]) < 1e-5
+    assert rel_err(q, g["q"]) < 1e-9
     assert np.array_equal(np.argmax(q, axis=1), np.argmax(g["q"], axis=1))
 
 
@@ -427,13 +427,13 @@ def test_online_path_calls_at_T256():
     resp = np.zeros(n)
     resp[members] = 1.0
     q, q_lat = m.full_pass_weighted(xs, y[:, :, None], resp)
-    tol = 1e-6
+    tol = 1e-8      # observed 1.0e-9 (T = 256, 2 x 256-step recursion behind every number)
     assert m.indexes == members and float(m.internal_params.n0) == float(g["n0"])
     assert rel_err(q.cpu().numpy(), g["q_shared"]) < tol
     assert rel_err(q_lat.cpu().numpy()[members], g["q_lat"][members]) < tol
     S = m.Sigma[-1].cpu().numpy()
-    assert np.allclose(np.diag(S), g["Sigma_last_diag"], rtol=tol) and np.allclose(S[7], g["Sigma_last_row7"], rtol=tol, atol=tol * np.abs(S).max())
-    assert np.allclose(m.f_star_sm[-1].cpu().numpy()[:, 0], g["f_star_sm_last"], rtol=tol, atol=tol * np.abs(g["f_star_sm_last"]).max())
+    assert np.allclose(np.diag(S), g["Sigma_last_diag"], rtol=tol) and relclose(S[7], g["Sigma_last_row7"], tol)
+    assert relclose(m.f_star_sm[-1].cpu().numpy()[:, 0], g["f_star_sm_last"], tol)
     assert abs(float(m.return_LDS_param_likelihood()) - float(g["lds_lik"])) <= tol * abs(float(g["lds_lik"]))
     for j in (0, 8, 9):
         assert abs(float(m.log_sq_error(xs[j], y[j][:, None], i=-1)) - g["lse_last_shared"][j]) <= tol * abs(g["lse_last_shared"][j])
@@ -442,8 +442,8 @@ def test_online_path_calls_at_T256():
         assert abs(v - g["lse_last_irr"][k]) <= tol * abs(g["lse_last_irr"][k])
     f, c = m.posterior_weighted(xs[8], y[8][:, None], 1.0)
     c = c.cpu().numpy()
-    assert np.allclose(f.cpu().numpy()[:, 0], g["pw_f"], rtol=tol, atol=tol * np.abs(g["pw_f"]).max())
-    assert np.allclose(np.diag(c), g["pw_cov_diag"], rtol=tol) and np.allclose(c[100], g["pw_cov_row100"], rtol=tol, atol=tol * np.abs(c).max())
+    assert relclose(f.cpu().numpy()[:, 0], g["pw_f"], tol)
+    assert np.allclose(np.diag(c), g["pw_cov_diag"], rtol=tol) and relclose(c[100], g["pw_cov_row100"], tol)
     means, covs, C, Sigma = m.smoother_weighted(xs[8], y[8][:, None], 1.0)
     v = m.log_sq_error(xs[8], y[8][:, None], mean=means[-1], cov=covs[-1], C=C[-1], Sigma=Sigma[-1], i=0, first=True)
     assert abs(float(v) - float(g["lse_candidate"])) <= tol * abs(float(g["lse_candidate"]))
