@@ -428,13 +428,14 @@ def gen_offline(tag, rec, n, stride):
 
 
 # ------------------------------------- drop-in surface: reload_model_from_labels + cluster_new_batch (record 102)
-def gen_reload(tag, rec, n=None):
+def gen_reload(tag, rec, n=None, leads=(0,)):
     """What hdpgpc/tests/test_offline_multi_output_load.py:74-85 does, on lead 0 with theta injected: rebuild the model from
     the record's annotation labels (one full_pass_weighted per class), then classify the same batch with the frozen
     models (cluster_new_batch, learning=False: M x N log_sq_error(i=-1) calls -> LogLik -> forward / backward ->
     one-hot arg-max)."""
-    data = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:, :, [0]]
+    data = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:, :, list(leads)]
     labels = np.load(os.path.join(REF, "data", "mitbih", f"{rec}_labels.npy"))
+    D = len(leads)                # D = 2 is the driver as written (both leads; SNR-weighted combination of the leads)
     if n is not None:
         data, labels = data[:n], labels[:n]
     data = np.ascontiguousarray(data)
@@ -445,7 +446,7 @@ def gen_reload(tag, rec, n=None):
     noise_warp = std * 0.1
     xb = np.arange(float(T))[:, None]
     x_trains = np.array([xb] * N)
-    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=D, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
                      bound_lengthscale=(1.0, 20.0), ini_gamma=gamma, ini_sigma=sigma, ini_outputscale=300.0,
                      noise_warp=noise_warp, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
                      bound_noise_warp=(noise_warp * 0.1, noise_warp * 0.2), warp_updating=False, method_compute_warp="greedy",
@@ -459,21 +460,24 @@ def gen_reload(tag, rec, n=None):
     lab = np.array([np.where(vals == l)[0] for l in labels_num]).squeeze()
     sw.reload_model_from_labels(x_trains, data, lab, M)
     new_labels = sw.cluster_new_batch(x_trains, data)
-    out = {"y": data[..., 0], "x_basis": xb[:, 0], "labels": lab.astype(np.int64), "M": np.array(M),
+    first = (lambda a: a[..., 0]) if D == 1 else (lambda a: a)      # the one-lead fixture keeps its round-2 layout
+    out = {"y": first(data), "x_basis": xb[:, 0], "labels": lab.astype(np.int64), "M": np.array(M),
            "estimators": np.array([std, std_dif, bound_sigma[0], bound_sigma[1], bound_gamma[0], bound_gamma[1]]),
            "sigma": np.array(sigma), "gamma": np.array(gamma), "theta_inject": np.array(THETA_INJECT),
            "new_labels": npy(new_labels).astype(np.int64), "transTheta": npy(sw.transTheta), "startTheta": npy(sw.startTheta),
-           "rho": npy(sw.rho), "omega": npy(sw.omega), "q_last": npy(sw.q_last)[:, :, 0], "q_lat_last": npy(sw.q_lat_last)[:, :, 0],
+           "rho": npy(sw.rho), "omega": npy(sw.omega), "q_last": first(npy(sw.q_last)), "q_lat_last": first(npy(sw.q_lat_last)),
            "resp_assigned": npy(sw.resp_assigned[-1]).astype(np.int64)}
     # the q matrix cluster_new_batch scored (frozen last states, i = -1) for diagnostics of the arg-max margin
     xt, yt = torch.from_numpy(x_trains), torch.from_numpy(data)
-    qn = np.zeros((N, M))
-    for m in range(M):
-        g = sw.gpmodels[0][m]
-        qn[:, m] = [float(g.log_sq_error(xt[i], yt[i], i=-1)) for i in range(N)]
-        out[f"m{m}_theta"] = kernel_theta(g.gp.kernel)
-        out[f"m{m}_n_members"] = np.array(len(g.indexes))
-    out["q_new"] = qn
+    qn = np.zeros((N, M, D))
+    for ld in range(D):
+        for m in range(M):
+            g = sw.gpmodels[ld][m]
+            qn[:, m, ld] = [float(g.log_sq_error(xt[i], yt[i][:, [ld]], i=-1)) for i in range(N)]
+            if ld == 0:
+                out[f"m{m}_theta"] = kernel_theta(g.gp.kernel)
+                out[f"m{m}_n_members"] = np.array(len(g.indexes))
+    out["q_new"] = first(qn)
     np.savez_compressed(os.path.join(OUT, f"reload_{tag}.npz"), **out)
     print(f"reload_{tag}: N={N} M={M} counts={[len(g.indexes) for g in sw.gpmodels[0]]} "
           f"changed labels={int(np.sum(out['new_labels'] != lab))}")
@@ -618,4 +622,6 @@ if __name__ == "__main__":
         gen_producer_extra()
     if "reload" in which:
         gen_reload("r102", "102")
+    if "reload2" in which:
+        gen_reload("r102_2leads", "102", n=700, leads=(0, 1))
     print("done")
