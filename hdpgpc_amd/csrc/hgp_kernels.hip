@@ -811,10 +811,13 @@ __global__ __launch_bounds__(256) void k_add_diag_mean(const double* __restrict_
 // The gains J_t, the predictive covariances P_t and A_t m_t only depend on the filtered states and are batched by the
 // caller; what remains is, for t = n-2 .. 0:
 //     m_t <- m_t + J_t (m_{t+1} - A_t m_t),      C_t <- C_t + J_t (C_{t+1} - P_t) J_t^T.
-// One workgroup walks the chain: J_t and D = C_{t+1} - P_t are staged in LDS (row pitch 100 doubles), X = J D is
-// formed tile-wise on the matrix core (each wave 9 of the 36 tiles, kept in registers until D is dead, then written
-// over it), then C_t + X J^T.  T <= 96.  C_{t+1} and m_{t+1} were written by the previous iteration of this same
-// workgroup: they are re-read with agent-scope loads behind a fence + barrier.
+// One workgroup of 12 waves walks the chain; wave w owns the output tiles w, w + 12, w + 24 of the 6 x 6 tile grid.
+// What crosses a step stays on chip: the new C_t tiles are still in the registers of the wave that formed them when the
+// next step needs them as C_{t+1} (D = C_{t+1} - P_t is formed tile-wise in registers and written to LDS), m_t sits in
+// LDS; and everything the NEXT step reads from memory (J, P, C, A m, m of step t - 1: filtered quantities, independent of
+// the recursion) is requested before the two product phases of the current step.  Per step: stage J and D in LDS (row
+// pitch 100 doubles), X = J D on the matrix core (kept in registers until D is dead, then written over it), C_t + X J^T.
+// The floor is the matrix core of ONE compute unit: 2 x 36 tiles x 24 MFMAs x 64 cycles / 4 SIMDs = 27.6 k cycles per step.
 struct RtsArgs {
   const double* J;    // [n-1,T,T]
   const double* P;    // [n-1,T,T]
@@ -824,10 +827,6 @@ struct RtsArgs {
   int n, T;
 };
 
-__device__ __forceinline__ double ld_agent(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 constexpr int RTS_WAVES = 12;   // three waves per SIMD: the LDS operand latency of one hides under the MFMAs of the others
 
 __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
@@ -835,7 +834,8 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Jl = smem;                    // [96][PITCH]
   double* Dl = Jl + 96 * PITCH;         // [96][PITCH]  D, then X
-  double* vl = Dl + 96 * PITCH;         // [96]
+  double* vl = Dl + 96 * PITCH;         // [96]  m_{t+1} - A_t m_t
+  double* ml = vl + 96;                 // [96]  m_{t+1} (smoothed), then m_t
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = a.T;
@@ -844,47 +844,79 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
     Jl[i] = 0.0;
     Dl[i] = 0.0;
   }
-  if (tid < 96) vl[tid] = 0.0;
-  __syncthreads();
-  for (int t = a.n - 2; t >= 0; --t) {
-    const double* Jt = a.J + (size_t)t * tt;
-    const double* Pt = a.P + (size_t)t * tt;
-    const double* Cn = a.Cv + (size_t)(t + 1) * tt;
-    double* Ct = a.Cv + (size_t)t * tt;
-    // staging: wave w takes rows w, w + 12, ...; a lane covers columns lane and lane + 64.  Four rows (24 loads per
-    // lane) are in flight at once - the plain strided loop serialised one load latency per element.
-#pragma unroll 1
-    for (int r0 = wave; r0 < T; r0 += 4 * RTS_WAVES) {
-      double jv[4][2], cv[4][2], pv[4][2];
+  if (tid < 96) {
+    vl[tid] = 0.0;
+    ml[tid] = (tid < T) ? a.M[(size_t)(a.n - 1) * T + tid] : 0.0;
+  }
+  // tile (I, Jc) = wave + 12 i of a row-major [T,T] matrix, accumulator layout, zero outside
+  auto load_tiles = [&](const double* __restrict__ X, d4 (&v)[3]) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = r0 + RTS_WAVES * u;
+    for (int i = 0; i < 3; ++i) {
+      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int q = lane + 64 * h;
-          const bool ok = r < T && q < T;
-          const long i = (long)r * T + q;
-          jv[u][h] = ok ? Jt[i] : 0.0;
-          pv[u][h] = ok ? Pt[i] : 0.0;
-          cv[u][h] = ok ? ld_agent(Cn + i) : 0.0;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = r0 + RTS_WAVES * u;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int q = lane + 64 * h;
-          if (r < T && q < T) {
-            Jl[r * PITCH + q] = jv[u][h];
-            Dl[r * PITCH + q] = cv[u][h] - pv[u][h];
-          }
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r, col = 16 * Jc + c;
+        v[i][r] = (row < T && col < T) ? X[(size_t)row * T + col] : 0.0;
       }
     }
-    if (tid < T) vl[tid] = ld_agent(a.M + (size_t)(t + 1) * T + tid) - a.AM[(size_t)t * T + tid];
+  };
+  // rows wave, wave + 12, ... of J (8 rows per wave), columns lane and lane + 64
+  auto load_rows = [&](const double* __restrict__ X, double (&v)[8][2]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = wave + RTS_WAVES * u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int q = lane + 64 * h;
+        v[u][h] = (r < T && q < T) ? X[(size_t)r * T + q] : 0.0;
+      }
+    }
+  };
+  d4 cn[3], pt[3], ct[3];
+  double jv[8][2];
+  double am = 0.0, mt = 0.0;
+  load_tiles(a.Cv + (size_t)(a.n - 1) * tt, cn);          // C_{n-1}: the last filtered state is its own smoothed state
+  {
+    const int t = a.n - 2;
+    load_rows(a.J + (size_t)t * tt, jv);
+    load_tiles(a.P + (size_t)t * tt, pt);
+    load_tiles(a.Cv + (size_t)t * tt, ct);
+    if (tid < T) {
+      am = a.AM[(size_t)t * T + tid];
+      mt = a.M[(size_t)t * T + tid];
+    }
+  }
+  __syncthreads();
+  for (int t = a.n - 2; t >= 0; --t) {
+    // ---- stage J_t (rows) and D = C_{t+1} - P_t (my tiles), v = m_{t+1} - A_t m_t
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = wave + RTS_WAVES * u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int q = lane + 64 * h;
+        if (r < T && q < T) Jl[r * PITCH + q] = jv[u][h];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Dl[(16 * I + g + 4 * r) * PITCH + 16 * Jc + c] = cn[i][r] - pt[i][r];
+    }
+    const double mt_cur = mt;
+    if (tid < T) vl[tid] = ml[tid] - am;
     __syncthreads();
-    // X = J D : tile (I, Jc) = wave + 12 i
+    // ---- requests of step t - 1 (filtered quantities only): in flight under both product phases
+    if (t > 0) {
+      load_rows(a.J + (size_t)(t - 1) * tt, jv);
+      load_tiles(a.P + (size_t)(t - 1) * tt, pt);
+      if (tid < T) {
+        am = a.AM[(size_t)(t - 1) * T + tid];
+        mt = a.M[(size_t)(t - 1) * T + tid];
+      }
+    }
+    // ---- X = J D
     d4 X[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -894,40 +926,49 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
       for (int k = 0; k < 96; k += 4) acc = mfma(Jl[(16 * I + c) * PITCH + k + g], Dl[(k + g) * PITCH + 16 * Jc + c], acc);
       X[i] = acc;
     }
-    // m_t += J v  (thread = row)
-    {   // eight lanes per row, 12 columns each, summed with DPP-free shuffles inside the 8-lane group
+    // ---- m_t += J v : eight lanes per row, 12 columns each, summed inside the 8-lane group
+    double mnew = 0.0;
+    {
       const int row = tid >> 3, part = tid & 7;
-      double s = 0.0;
+      double sv = 0.0;
       if (row < T)
-        for (int j = part; j < T; j += 8) s = fma(Jl[row * PITCH + j], vl[j], s);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if (row < T && part == 0) a.M[(size_t)t * T + row] += s;
+        for (int j = part; j < T; j += 8) sv = fma(Jl[row * PITCH + j], vl[j], sv);
+      sv += __shfl_xor(sv, 1, 64);
+      sv += __shfl_xor(sv, 2, 64);
+      sv += __shfl_xor(sv, 4, 64);
+      mnew = sv;                             // valid in the lanes with part == 0
     }
-    __syncthreads();                       // every wave has finished reading D
+    __syncthreads();                         // every wave has finished reading D, v and m_{t+1}
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
 #pragma unroll
       for (int r = 0; r < 4; ++r) Dl[(16 * I + g + 4 * r) * PITCH + 16 * Jc + c] = X[i][r];
     }
+    if ((tid & 7) == 0 && (tid >> 3) < T) vl[tid >> 3] = mnew;        // J v, row-indexed (v is dead)
     __syncthreads();
-    // C_t += X J^T
+    if (tid < T) {                           // m_t = (filtered m_t) + J v: out to memory, and kept for the next step
+      const double m = mt_cur + vl[tid];
+      ml[tid] = m;
+      a.M[(size_t)t * T + tid] = m;
+    }
+    // ---- C_t = (filtered C_t) + X J^T : the result stays in cn for the next step
+    double* Ct = a.Cv + (size_t)t * tt;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      d4 acc = ct[i];
 #pragma unroll 4
       for (int k = 0; k < 96; k += 4) acc = mfma(Dl[(16 * I + c) * PITCH + k + g], Jl[(16 * Jc + c) * PITCH + k + g], acc);
+      cn[i] = acc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * I + g + 4 * r, col = 16 * Jc + c;
-        if (row < T && col < T) Ct[(size_t)row * T + col] += acc[r];
+        if (row < T && col < T) Ct[(size_t)row * T + col] = acc[r];
       }
     }
-    __threadfence();
-    __syncthreads();                       // C_t, m_t visible; LDS free for the next step
+    if (t > 0) load_tiles(a.Cv + (size_t)(t - 1) * tt, ct);          // consumed one whole step later
+    __syncthreads();                         // LDS free for the next step; m_t visible
   }
 }
 
@@ -2870,7 +2911,7 @@ int hgp_rts_chain_f64(const double* J, const double* P, const double* AM, double
   if (T > 96) return -2;
   if (n < 2) return 0;
   RtsArgs a{J, P, AM, M, Cv, n, T};
-  const size_t lds = sizeof(double) * (2 * 96 * 100 + 96);
+  const size_t lds = sizeof(double) * (2 * 96 * 100 + 2 * 96);
   if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_rts_chain), lds)) return rc_;
   hipLaunchKernelGGL(k_rts_chain, dim3(1), dim3(64 * RTS_WAVES), lds, (hipStream_t)stream, a);
   return launch_status();
