@@ -279,10 +279,12 @@ def main():
         kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)]))
         flops = (hi - lo) * k_cl * algorithmic_flops_per_eval(t_len)          # per launch on this rank
         achieved = flops / (kern_ms * 1e-3) / 1e12
-        traffic = None
+        traffic = mfma_per_pair = None
         tf = os.path.join(ROOT, "profiles", "pairs_traffic.json")
         if world == 1 and os.path.exists(tf):
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            tfj = json.load(open(tf))
+            traffic = tfj.get("hbm_bytes_per_launch")
+            mfma_per_pair = tfj.get("mfma_f64_instructions_per_pair")
         res = {
             "metric": "GP log-lik evals/sec (NxK batch, T-point segments)",
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -298,6 +300,12 @@ def main():
                          "kernel": kern, "kernel_ms": kern_ms, "pairs_per_launch": (hi - lo) * k_cl,
                          "algorithmic_flops_per_eval": algorithmic_flops_per_eval(t_len)},
         }
+        if mfma_per_pair:   # what the kernel EXECUTES (PMC count): cov_f = K** + E^T M' E is formed per pair before the one
+            # Cholesky the yardstick counts, so `frac` cannot exceed algorithmic / executed even at 100 % MFMA-busy
+            ex = mfma_per_pair * 2048.0
+            res["roofline"]["executed_flops_per_eval"] = ex
+            res["roofline"]["executed_frac"] = achieved / FP64_MFMA_PEAK_TFLOPS * ex / algorithmic_flops_per_eval(t_len)
+            res["roofline"]["frac_ceiling"] = algorithmic_flops_per_eval(t_len) / ex
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_shared_grid(dev, ops)
             res["secondary_large_T"] = secondary_large_T(dev, ops, synth)
