@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC   = hdpgpc_amd/csrc
-SRCS   = $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
+SRCS   = $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
 HDR    = $(CSRC)/tile_f64.hpp $(CSRC)/hgp_internal.hpp include/hdpgpc_hip.h
 OBJDIR = build/obj
 OBJS   = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
@@ -27,8 +27,8 @@ stamps: $(SRCS) $(HDR)
 # right-hand-side row update, with the pre-round-2 round-robin dealing (races) and with the owner dealing (immune)
 raceprobe: $(SRCS) $(HDR)
 	mkdir -p build/probe
-	$(HIPCC) $(FLAGS) -DHGP_RACE_PROBE_DELAY -DHGP_RACE_PROBE_ROUNDROBIN -shared -o build/probe/libhgp_race_old.so $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
-	$(HIPCC) $(FLAGS) -DHGP_RACE_PROBE_DELAY -shared -o build/probe/libhgp_race_new.so $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
+	$(HIPCC) $(FLAGS) -DHGP_RACE_PROBE_DELAY -DHGP_RACE_PROBE_ROUNDROBIN -shared -o build/probe/libhgp_race_old.so $(SRCS)
+	$(HIPCC) $(FLAGS) -DHGP_RACE_PROBE_DELAY -shared -o build/probe/libhgp_race_new.so $(SRCS)
 
 # every workgroup barrier followed by a pseudo-random per-wave delay: run the GPU tests with HGP_LIB pointing at it
 racestress: $(SRCS) $(HDR)

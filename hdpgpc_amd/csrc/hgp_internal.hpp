@@ -73,3 +73,39 @@ int hgp_internal_lat_error_wave(const double* f_cur, const double* f_prev, const
                                 int T, int b, double* out, int32_t* info, hipStream_t st);
 int hgp_internal_mniw_wave(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov, const double* scale,
                            int scale_is_diagonal, long prior_stride, int T, int b, double* out, int32_t* info, hipStream_t st);
+
+// arguments of the explicit-operator pair kernels (hgp_pairs.hip)
+struct PairsArgs {
+  const double* x;
+  const double* y;
+  int N, Ts;
+  const double* xb;
+  int T;
+  const double* Mp;
+  const double* ap;
+  const double* scal;
+  const int32_t* perm;   // sorted position -> original cluster id
+  int kbeg, kend;        // range of sorted positions sharing one length-scale
+  double ell;
+  const double* first_noise;
+  const int32_t* sel;    // optional [N]: segment n is scored against cluster sel[n] only; outputs are then [N]
+#ifdef HGP_STAMPS
+  unsigned long long* stamps;
+#endif
+  int K;
+  double* out_quad;
+  double* out_logdet;
+  int32_t* out_info;
+  // cooperative kernel only: global scratch for the E blocks that do not fit its LDS slots (dense grids)
+  double* escr;          // [nscr][escr_stride]
+  int32_t* eflags;       // [nscr] 0 = free
+  int nscr;
+  long escr_stride;
+};
+
+#ifdef HGP_STAMPS
+extern unsigned long long* hgp_internal_stamp_dev;
+#endif
+int hgp_internal_pairs_fast(const PairsArgs& a, int NB, bool coop, bool four_wave, hipStream_t st);
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device), under a lock
+int hgp_internal_ensure_dynamic_lds(const void* fn, size_t bytes);

@@ -1,0 +1,1082 @@
+// a2 + a5, the per-pair kernels of hgp_loglik_pairs_f64 (explicit-operator evaluation of cov_f): k_pairs<NB> (T <= 128, one
+// wavefront per pair), k_pairs_coop<NB> (4 waves per pair) and k_pairs_cooph<NB> (NB/2 waves per pair) for T <= 256.
+// The plan (per-cluster operators) and the C-ABI live in hgp_kernels.hip; the solve-based kernel in hgp_pairs_acc.hip.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "hgp_internal.hpp"
+#include "tile_f64.hpp"
+
+using namespace hgp;
+
+namespace {
+
+// -------------------------------------------------------------------------------------- a2 + a5
+
+// PAIRS_CUT (block-wise cut-off of E and K**): hgp_internal.hpp
+
+template <int NB>
+constexpr size_t pairs_lds_bytes() {
+  return sizeof(double) * ((size_t)(16 * NB) * (16 * NB) + 3 * 16 * NB + WAVES * DIAG_SCR + WAVES * 16 * NB) +
+         sizeof(int) * 16;
+}
+
+// One workgroup per segment n; its 4 waves take the clusters of the length-scale group round-robin.
+// E_n = exp(-0.5 ((xb_k - x_j)/ell)^2) is built once per workgroup in LDS (active 16x16 blocks only) and shared by
+// the waves; each wave then evaluates one (segment, cluster) pair entirely in its own registers:
+//   cov = c R_n + noise I + E^T M'_k E   (two MFMA sweeps per column panel, the first result feeding the second
+//   straight from its accumulators), regularise, factor (wave_factor), eliminate d on the VALU, reduce.
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
+  constexpr int TP = 16 * NB;
+  constexpr int NH = NB / 2;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* E = smem;               // [TP][TP]: row k = basis point, column j = segment point
+  double* xs = E + TP * TP;       // segment grid / ell
+  double* ys = xs + TP;
+  double* xbs = ys + TP;          // basis grid / ell
+  const int tid = threadIdx.x, wave = tid >> 6;
+  double* scr = xbs + TP + wave * DIAG_SCR;
+  double* dv = xbs + TP + WAVES * DIAG_SCR + wave * TP;
+  int* amask = reinterpret_cast<int*>(xbs + TP + WAVES * DIAG_SCR + WAVES * TP);   // bit Kt of amask[J]: block (Kt, J) of E active
+  const int n = blockIdx.x;
+  const int T = a.T, Ts = a.Ts;
+
+  // Padding (i >= Ts, k >= T) uses far-apart sentinels instead of bounds predicates: every kernel entry that
+  // involves a padded point is then exp(-huge) = 0 by itself (all differences stay finite: < 3e152).
+  for (int i = tid; i < TP; i += 64 * WAVES) {
+    xs[i] = (i < Ts) ? a.x[(size_t)n * Ts + i] / a.ell : 1e150 * (double)(1 + i);
+    ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
+    xbs[i] = (i < T) ? a.xb[i] / a.ell : -1e150 * (double)(1 + i);
+  }
+  int* kmask = amask + 8;   // bit I of kmask[J]: tile (I, J) of K** has an entry above the cut-off (I <= J)
+  if (tid < 16) amask[tid] = 0;
+  __syncthreads();
+  {
+    const int lane = tid & 63, g = lane >> 4, c = lane & 15;
+    for (int blk = wave; blk < NB * NB; blk += WAVES) {
+      const int Kt = blk / NB, Jb = blk % NB;
+      const int j = 16 * Jb + c;
+      double h[4];
+      bool near = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * Kt + g + 4 * r;
+        const double u = xbs[k] - xs[j];
+        h[r] = 0.5 * (u * u);
+        near = near || (h[r] < PAIRS_CUT);
+      }
+      if (__any(near)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) E[(16 * Kt + g + 4 * r) * TP + j] = exp(-h[r]);
+        if (lane == 0) atomicOr(&amask[Jb], 1 << Kt);
+      }
+    }
+    for (int t = wave; t < NB * NB; t += WAVES) {   // same test for the tiles of K** (upper ones)
+      const int I = t / NB, J = t % NB;
+      if (I > J) continue;
+      bool near = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double u = xs[16 * I + g + 4 * r] - xs[16 * J + c];
+        near = near || (0.5 * (u * u) < PAIRS_CUT);
+      }
+      if (__any(near) && lane == 0) atomicOr(&kmask[J], 1 << I);
+    }
+  }
+  __syncthreads();
+
+  HGP_STAMP_DECL
+  for (int kk = a.kbeg + wave; kk < a.kend; kk += WAVES) {
+    const int lane = launder(tid) & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const int kc = a.perm[kk];
+    if (a.sel && a.sel[n] != kc) continue;
+    HGP_T0();
+    const double* sc = a.scal + 8 * kc;
+    if (sc[7] != 0.0) continue;   // ill-conditioned K~: this cluster is scored by the solve-based kernel (hgp_pairs_acc.hip)
+    const double cc = sc[0], noise = sc[2];
+    const bool iso = sc[3] != 0.0;
+    const size_t oidx = a.sel ? (size_t)n : (size_t)n * a.K + kc;
+    const double fn = a.first_noise ? a.first_noise[oidx] : 0.0;
+    int msk[NB], kmsk[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      msk[J] = __builtin_amdgcn_readfirstlane(amask[J]);
+      kmsk[J] = __builtin_amdgcn_readfirstlane(kmask[J]);
+    }
+
+    // d = y - E^T a'   (a' = c K~^{-1} mean), column block by column block over the active blocks of E
+    const double* apk = a.ap + (size_t)kc * TP;
+    double apr[NB][4];   // a'[16 Kt + g + 4 r]: one batch of L2 loads per pair instead of one per block
+#pragma unroll
+    for (int Kt = 0; Kt < NB; ++Kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) apr[Kt][r] = apk[16 * Kt + g + 4 * r];
+    double dsq = 0.0;
+#pragma unroll
+    for (int Jb = 0; Jb < NB; ++Jb) {
+      double p = 0.0;
+#pragma unroll
+      for (int Kt = 0; Kt < NB; ++Kt) {
+        if (msk[Jb] & (1 << Kt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p = fma(E[(16 * Kt + g + 4 * r) * TP + 16 * Jb + c], apr[Kt][r], p);
+        }
+      }
+      p = xrow_sum(p);
+      if (g == 0) {
+        const int j = 16 * Jb + c;
+        const double d = ys[j] - p;     // padded entries: 0 - 0
+        dv[j] = d;
+        dsq = fma(d, d, dsq);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    HGP_ACC(0);
+
+    if (iso) {   // GPI.py:497-498: cov_f = mean(diag Sigma) I
+      double v = sc[4] + fn;
+      double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
+      double q = wave_sum(dsq) / v2;
+      if (lane == 0) {
+        a.out_quad[oidx] = q;
+        if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
+        if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
+      }
+      continue;
+    }
+
+    // cov tiles (upper).  Each tile starts as K** = c exp(-0.5 (x_i - x_j)^2 / ell^2) + noise I (the one-argument
+    // kernel call, GPI.py:476), computed right before the first MFMA that accumulates into it.
+    d4 cov[NB * (NB + 1) / 2];
+    // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
+    // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
+    const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP;   // + column offset inside HGP_FILL (interleaved)
+    // Sweep-1 operand ring: 4 slots of half a k-block each (2 k-steps: 2 x NH rows of M' from L2 + 2 values of E
+    // from LDS).  A slot is refilled right after its MFMAs are issued, i.e. three half-blocks (about 1.5k cycles
+    // of MFMA) before it is used again; the first two blocks of the NEXT sweep are requested at the end of a sweep.
+    double ra[4][2][NH], re[4][2];
+    int kA = -1, kB = -1, m = msk[0];
+#define HGP_FILL(slot, half, blk, Mptr, Jcol)                                                               \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                        \
+    const double* row_ = (Mptr) + (size_t)(16 * (blk) + 4 * (2 * (half) + s_)) * TP;                        \
+    _Pragma("unroll") for (int P_ = 0; P_ < NH / 2; ++P_) {                                                 \
+      const d2 t_ = *reinterpret_cast<const d2*>(row_ + 32 * P_ + 2 * c);                                   \
+      ra[slot][s_][2 * P_] = t_[0];                                                                         \
+      ra[slot][s_][2 * P_ + 1] = t_[1];                                                                     \
+    }                                                                                                       \
+    if (NH & 1) ra[slot][s_][NH - 1] = row_[16 * (NH - 1) + c];                                             \
+    re[slot][s_] = E[(16 * (blk) + 4 * (2 * (half) + s_) + g) * TP + 16 * (Jcol) + c];                      \
+  }
+#define HGP_MMA(slot)                                                                                       \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                        \
+    _Pragma("unroll") for (int I_ = 0; I_ < NH; ++I_) BJ[I_] = mfma(ra[slot][s_][I_], re[slot][s_], BJ[I_]); \
+  }
+    if (m) {
+      kA = __builtin_ctz(m);
+      m &= m - 1;
+      HGP_FILL(0, 0, kA, Mbase, 0)
+      HGP_FILL(1, 1, kA, Mbase, 0)
+    }
+    if (m) {
+      kB = __builtin_ctz(m);
+      m &= m - 1;
+      HGP_FILL(2, 0, kB, Mbase, 0)
+      HGP_FILL(3, 1, kB, Mbase, 0)
+    }
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // sweep 1: BJ = M'[16 NH h .. , :] E[:, J] over the ACTIVE k-blocks of column panel J.  M' is symmetric, so
+        // row-tile I of the A operand is read as M'[k][16 I + c]: 128 contiguous bytes per 16 lanes, from L2.
+        const double* Mk = Mbase + 16 * NH * h;
+        d4 BJ[NH];
+#pragma unroll
+        for (int I = 0; I < NH; ++I) BJ[I] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma nounroll
+        while (kA >= 0) {
+          int kC = -1, kD = -1;
+          if (m) {
+            kC = __builtin_ctz(m);
+            m &= m - 1;
+          }
+          HGP_MMA(0)
+          if (kC >= 0) { HGP_FILL(0, 0, kC, Mk, J) }
+          HGP_MMA(1)
+          if (kC >= 0) { HGP_FILL(1, 1, kC, Mk, J) }
+          if (kB < 0) {
+            kA = kC;
+            break;
+          }
+          if (m) {
+            kD = __builtin_ctz(m);
+            m &= m - 1;
+          }
+          HGP_MMA(2)
+          if (kD >= 0) { HGP_FILL(2, 0, kD, Mk, J) }
+          HGP_MMA(3)
+          if (kD >= 0) { HGP_FILL(3, 1, kD, Mk, J) }
+          kA = kC;
+          kB = kD;
+        }
+        kA = -1;
+        kB = -1;
+        if (!(J == NB - 1 && h == 1)) {   // request the first two active blocks of the next sweep now
+          const int Jn = (h == 0) ? J : J + 1, hn = (h == 0) ? 1 : 0;
+          const int Jc = Jn < NB ? Jn : 0;
+          const double* Mn = Mbase + 16 * NH * hn;
+          m = msk[Jc];
+          if (m) {
+            kA = __builtin_ctz(m);
+            m &= m - 1;
+            HGP_FILL(0, 0, kA, Mn, Jc)
+            HGP_FILL(1, 1, kA, Mn, Jc)
+          }
+          if (m) {
+            kB = __builtin_ctz(m);
+            m &= m - 1;
+            HGP_FILL(2, 0, kB, Mn, Jc)
+            HGP_FILL(3, 1, kB, Mn, Jc)
+          }
+        }
+        HGP_ACC(1);
+        if (h == 0) {
+#pragma unroll
+          for (int I = 0; I <= J; ++I) {
+            const int ln = launder(lane);
+            d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
+            if (kmsk[J] & (1 << I)) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
+                kt[r] = cc * exp(-0.5 * (u * u));
+              }
+            }
+            if (I == J) {   // exact diagonal of the one-argument kernel call; identity on the padding
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if ((ln >> 4) + 4 * r == (ln & 15)) kt[r] = (16 * I + (ln & 15) < Ts) ? cc + noise : 1.0;
+            }
+            cov[tix(I, J, NB)] = kt;
+          }
+        }
+        HGP_ACC(2);
+        // sweep 2: cov[I][J] += E[rows h, I]^T BJ over the active blocks (Kt, I) of E; the B operand is the
+        // accumulator of sweep 1, untouched.
+#pragma unroll
+        for (int Kt = 0; Kt < NH; ++Kt) {
+#pragma unroll
+          for (int I = 0; I <= J; ++I) {
+            // operands are read unconditionally (an inactive block holds stale LDS bytes that are never multiplied):
+            // the reads can then be issued ahead of the branch and overlap the previous block's MFMAs
+            double af[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) af[r] = E[(16 * (NH * h + Kt) + 4 * r + g) * TP + 16 * I + c];
+            if (msk[I] & (1 << (NH * h + Kt))) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) cov[tix(I, J, NB)] = mfma(af[r], BJ[Kt][r], cov[tix(I, J, NB)]);
+            }
+          }
+        }
+        HGP_ACC(3);
+      }
+    }
+
+    // regularisation of the reference: +1e-6 I (GPI.py:501), + first, + 1e-8 mean|diag| I (GPI_model.py:83-87)
+    {
+      const double sh = 1e-6 + fn;
+      const double dm = diag_abs_mean<NB>(cov, Ts, lane, sh);
+      add_diag<NB>(cov, sh + 1e-8 * fmax(dm, F64_EPS), Ts, lane);
+    }
+    PivotAcc pa;
+    pa.init();
+    d4 Rnone[NB];
+    HGP_ACC(4);
+    const double q = wave_factor<NB, 2, (NB >= 8)>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
+    if (lane == 0) {
+      a.out_quad[oidx] = q;
+      if (a.out_logdet) a.out_logdet[oidx] = pa.logdet();
+      if (a.out_info) a.out_info[oidx] = pa.info;
+    }
+    HGP_ACC(5);
+#ifdef HGP_STAMPS
+    hgp_acc_[7] += pa.diag_cycles;
+#endif
+  }
+#ifdef HGP_STAMPS
+  if ((tid & 63) == 0 && a.stamps)
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
+#endif
+}
+
+// ------------------------------------------------------------ a2 + a5, cooperative: one workgroup per pair
+// For 128 < T <= 256 a pair does not fit one wave (136 tiles at T = 256).  Here the 4 waves of a workgroup share ONE
+// (segment, cluster) pair: the covariance tiles are dealt by block column in snake order (Coop::owner(J)), at most
+// 40 tiles = 320 VGPR per wave), each wave builds the tiles of its own block columns (K** + two MFMA sweeps, no
+// exchange), then the workgroup factors cooperatively (coop_factor: diagonal block by its owner, row panel and
+// trailing update by column owner, two barriers per step) with the single right-hand side d eliminated on the VALU.
+// E_n lives in LDS in COMPACT form: only the 16x16 blocks with an entry above the cut-off get a slot (2 KB each,
+// [slot][k-step][lane] = the MFMA operand order of both sweeps).  With the reference's length-scale (1.2 on a
+// unit-spaced grid) 3 NB - 2 blocks are active (46 at T = 256, 92 KB).  Blocks beyond the CAP slots are not stored:
+// their operands are recomputed (exp) where they are used - slower, but any grid / length-scale stays correct.
+// Row tiles of B = M' E[:, J] that no active block (Kt, I <= J) of sweep 2 reads are not computed at all.
+template <int NB>
+struct PairsCoop {
+  static constexpr int TP = 16 * NB;
+  static constexpr int CAP = (NB >= 12) ? 48 : (NB == 8 ? 24 : 16);
+  static constexpr size_t LDS_BYTES =
+      sizeof(double) * ((size_t)CAP * 256 + NB * 256 /*rowbuf*/ + 256 /*Wbuf*/ + TP /*dvec*/ + 3 * TP + DIAG_SCR + 16) +
+      sizeof(int) * (8 + 16 + 16 + 16 + 20 + NB * NB) + sizeof(double) * 4 * NB;
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
+  using C = Coop<NB>;
+  using PC = PairsCoop<NB>;
+  constexpr int TP = 16 * NB, CAP = PC::CAP, NQ = C::NQ;
+  constexpr int CH = (NB == 16) ? 2 : 4;   // row tiles of B[:, J] per pass (register budget: 40 resident tiles at NB = 16)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ec = smem;                    // [CAP][4][64]
+  double* rowbuf = Ec + CAP * 256;      // [NB][4][64]
+  double* Wbuf = rowbuf + NB * 256;
+  double* dvec = Wbuf + 256;            // d, then z = L^{-1} d
+  double* xs = dvec + TP;
+  double* ys = xs + TP;
+  double* xbs = ys + TP;
+  double* scr = xbs + TP;
+  double* red = scr + DIAG_SCR;         // 16 doubles
+  int* redi = reinterpret_cast<int*>(red + 16);   // 8
+  int* amask = redi + 8;                // bit Kt of amask[J]: block (Kt, J) of E active
+  int* kmask = amask + 16;              // bit I of kmask[J]: tile (I, J) of K** above the cut-off (I <= J)
+  int* pneed = kmask + 16;              // OR of amask[0..J]: row tiles of B[:, J] that sweep 2 reads
+  int* base = pneed + 16;               // first slot of column J (prefix sum of popcounts), base[NB] = total
+  int* slotblk = base + 20;             // slot -> (Kt << 8) | J
+  double* rng = reinterpret_cast<double*>(slotblk + NB * NB);   // [2 NB][lo, hi] of the real points of each 16-block
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.T, Ts = a.Ts;
+  const int Kg = a.kend - a.kbeg;
+
+  // block -> (segment, cluster).  Without `sel` the Kg clusters of the group are spread over the 8 XCDs (block b runs
+  // on XCD b % 8) so that each XCD's L2 keeps the operators of Kg / 8 clusters only.
+  int n, kc;
+  if (a.sel) {
+    n = blockIdx.x;
+    kc = a.sel[n];
+    bool mine = false;
+    for (int kk = a.kbeg; kk < a.kend; ++kk) mine = mine || (a.perm[kk] == kc);
+    if (!mine) return;
+  } else {
+    const int b = blockIdx.x;
+    int kk;
+    if ((Kg & 7) == 0) {
+      const int cpx = Kg >> 3, s = b >> 3;
+      kk = (b & 7) + 8 * (s % cpx);
+      n = s / cpx;
+    } else {
+      kk = b % Kg;
+      n = b / Kg;
+    }
+    kc = a.perm[a.kbeg + kk];
+  }
+  if (a.scal[8 * kc + 7] != 0.0) return;   // ill-conditioned K~: scored by the solve-based kernel (hgp_pairs_acc.hip)
+
+  HGP_STAMP_DECL
+  HGP_T0();
+  for (int i = tid; i < TP; i += 64 * WAVES) {   // sentinel padding as in k_pairs
+    xs[i] = (i < Ts) ? a.x[(size_t)n * Ts + i] / a.ell : 1e150 * (double)(1 + i);
+    ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
+    xbs[i] = (i < T) ? a.xb[i] / a.ell : -1e150 * (double)(1 + i);
+  }
+  if (tid < 16) {
+    amask[tid] = 0;
+    kmask[tid] = 0;
+  }
+  __syncthreads();
+  // Which 16x16 blocks of E (and tiles of K**) can hold an entry above the cut-off?  Decided from the data: the
+  // range [min, max] of the REAL points of every 16-block (padding excluded), then block (Kt, J) is active iff the
+  // two ranges are closer than the cut-off radius.  Exact for sorted grids, a superset otherwise (never drops a block).
+  for (int b16 = wave; b16 < 2 * NB; b16 += WAVES) {
+    const int B = (b16 < NB) ? b16 : b16 - NB;
+    const int i = 16 * B + c;
+    const bool real = (b16 < NB) ? (i < T) : (i < Ts);
+    const double v = (b16 < NB) ? xbs[i] : xs[i];
+    double lo = real ? v : __builtin_inf(), hi = real ? v : -__builtin_inf();
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+      lo = fmin(lo, __shfl_xor(lo, o, 64));
+      hi = fmax(hi, __shfl_xor(hi, o, 64));
+    }
+    if (lane == 0) {
+      rng[2 * b16] = lo;
+      rng[2 * b16 + 1] = hi;
+    }
+  }
+  __syncthreads();
+  bool actE = false;
+  int myKt = 0, myJb = 0;
+  if (tid < NB * NB) {
+    myKt = tid / NB;
+    myJb = tid % NB;
+    const double xlo = rng[2 * (NB + myJb)], xhi = rng[2 * (NB + myJb) + 1];
+    const double gE = fmax(0.0, fmax(rng[2 * myKt] - xhi, xlo - rng[2 * myKt + 1]));
+    actE = 0.5 * (gE * gE) < PAIRS_CUT;
+    if (actE) atomicOr(&amask[myJb], 1 << myKt);
+    if (myKt <= myJb) {
+      const double gK = fmax(0.0, fmax(rng[2 * (NB + myKt)] - xhi, xlo - rng[2 * (NB + myKt) + 1]));
+      if (0.5 * (gK * gK) < PAIRS_CUT) atomicOr(&kmask[myJb], 1 << myKt);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int s = 0, o = 0;
+    for (int J = 0; J < NB; ++J) {
+      base[J] = s;
+      s += __popc(amask[J]);
+      o |= amask[J];
+      pneed[J] = o;
+    }
+    base[NB] = s;
+  }
+  __syncthreads();
+  if (actE) slotblk[base[myJb] + __popc(amask[myJb] & ((1 << myKt) - 1))] = (myKt << 8) | myJb;
+  const int nslot = __builtin_amdgcn_readfirstlane(base[NB]);
+  // Dense grids: the blocks beyond the LDS slots go to a global scratch area of this workgroup.  Areas are handed out
+  // with a compare-and-swap on a flag array that has more entries than workgroups can be resident at once.
+  double* Eov = nullptr;
+  int my_area = -1;
+  if (nslot > CAP) {
+    if (tid == 0) {
+      int sidx = blockIdx.x % a.nscr;
+      while (atomicCAS(&a.eflags[sidx], 0, 1) != 0) sidx = (sidx + 1 == a.nscr) ? 0 : sidx + 1;
+      redi[7] = sidx;
+    }
+    __syncthreads();
+    my_area = redi[7];
+    Eov = a.escr + (size_t)my_area * a.escr_stride;
+  }
+  __syncthreads();
+  for (int slot = wave; slot < nslot; slot += WAVES) {
+    const int kj = __builtin_amdgcn_readfirstlane(slotblk[slot]);
+    const int Kt = kj >> 8, Jb = kj & 255;
+    double* dst = (slot < CAP) ? Ec + slot * 256 : Eov + (size_t)(slot - CAP) * 256;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double u = xbs[16 * Kt + 4 * s + g] - xs[16 * Jb + c];
+      dst[s * 64 + lane] = exp(-0.5 * (u * u));
+    }
+  }
+  __syncthreads();
+  // E[16 Kt + 4 s + g][16 Jb + c] of the block in `slot`: the B operand of sweep 1 (k-step s) and the A operand of sweep 2
+  // (the overflow read is a volatile global load on purpose: with two plain loads the compiler merges the branches
+  //  into ONE flat_load through a selected generic pointer, which costs the LDS path its ds_read and its wait counter)
+  auto e_op = [&](int slot, int s) -> double {
+    if (slot < CAP) return Ec[slot * 256 + s * 64 + lane];
+    return *reinterpret_cast<const volatile double*>(Eov + (size_t)(slot - CAP) * 256 + s * 64 + lane);
+  };
+  auto release_area = [&]() {
+    if (my_area >= 0) {
+      __syncthreads();
+      if (tid == 0) {
+        __threadfence();
+        atomicExch(&a.eflags[my_area], 0);
+      }
+    }
+  };
+
+  HGP_ACC(0);
+  const double* sc = a.scal + 8 * kc;
+  const double cc = sc[0], noise = sc[2];
+  const bool iso = sc[3] != 0.0;
+  const size_t oidx = a.sel ? (size_t)n : (size_t)n * a.K + kc;
+  const double fn = a.first_noise ? a.first_noise[oidx] : 0.0;
+
+  // d = y - E^T a'  (block columns dealt to the waves)
+  const double* apk = a.ap + (size_t)kc * TP;
+  double dsq = 0.0;
+  for (int Jb = wave; Jb < NB; Jb += WAVES) {
+    int m = __builtin_amdgcn_readfirstlane(amask[Jb]);
+    int slot = __builtin_amdgcn_readfirstlane(base[Jb]);
+    double p = 0.0;
+    while (m) {
+      const int Kt = __builtin_ctz(m);
+      m &= m - 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) p = fma(e_op(slot, s), apk[16 * Kt + 4 * s + g], p);
+      ++slot;
+    }
+    p = xrow_sum(p);
+    if (g == 0) {
+      const int j = 16 * Jb + c;
+      const double d = ys[j] - p;
+      dvec[j] = d;
+      dsq = fma(d, d, dsq);
+    }
+  }
+  HGP_ACC(1);
+  if (iso) {   // GPI.py:497-498: cov_f = mean(diag Sigma) I
+    dsq = wave_sum(dsq);
+    if (lane == 0) red[wave] = dsq;
+    __syncthreads();
+    if (tid == 0) {
+      const double v = sc[4] + fn;
+      const double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
+      a.out_quad[oidx] = (red[0] + red[1] + red[2] + red[3]) / v2;
+      if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
+      if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
+    }
+    release_area();
+    return;
+  }
+
+  int msk[NB], bas[NB];   // uniform copies for the statically indexed uses of sweep 2
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    msk[I] = __builtin_amdgcn_readfirstlane(amask[I]);
+    bas[I] = __builtin_amdgcn_readfirstlane(base[I]);
+  }
+  const double* Mk = a.Mp + (size_t)kc * TP * TP;   // plain row-major here (no tile-pair interleave)
+  d4 U[C::NT];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int J = C::col(q, wave);
+    const int mJ = __builtin_amdgcn_readfirstlane(amask[J]), bJ = __builtin_amdgcn_readfirstlane(base[J]);
+    const int kmJ = __builtin_amdgcn_readfirstlane(kmask[J]), need = __builtin_amdgcn_readfirstlane(pneed[J]);
+    // K** = c exp(-0.5 (x_i - x_j)^2) + noise I on my column (the one-argument kernel call, GPI.py:476)
+#pragma unroll
+    for (int I = 0; I < 4 * q + 4; ++I) {
+      const int ln = launder(lane);
+      d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
+      if (I <= J) {
+        if (kmJ & (1 << I)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
+            kt[r] = cc * exp(-0.5 * (u * u));
+          }
+        }
+        if (I == J) {   // exact diagonal; identity on the padding
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((ln >> 4) + 4 * r == (ln & 15)) kt[r] = (16 * I + (ln & 15) < Ts) ? cc + noise : 1.0;
+        }
+      }
+      U[C::loc(I, q)] = kt;
+    }
+    HGP_ACC(2);
+#pragma nounroll
+    for (int h = 0; h < NB / CH; ++h) {
+      const int nb4 = (need >> (CH * h)) & ((1 << CH) - 1);
+      if (!nb4) continue;
+      // sweep 1: BJ[i] = M'[rows of tile 4h + i, :] E[:, J] over the active blocks of column J.  M' is symmetric:
+      // the A operand of output row tile i, k-step s of block Kt is M'[16 Kt + 4 s + g][16 (4h + i) + c] (coalesced).
+      d4 BJ[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) BJ[i] = (d4){0.0, 0.0, 0.0, 0.0};
+      const double* Mh = Mk + (size_t)g * TP + 16 * CH * h + c;
+      double ra[2][4][CH], re[2][4];
+#define HGP_CFILL(buf, Kt_, slot_)                                                                  \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
+    const double* row_ = Mh + (size_t)(16 * (Kt_) + 4 * s_) * TP;                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) ra[buf][s_][i_] = row_[16 * i_];               \
+    re[buf][s_] = e_op((slot_), s_);                                                                 \
+  }
+#define HGP_CMMA(buf)                                                                               \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_)                                               \
+      if (nb4 & (1 << i_)) BJ[i_] = mfma(ra[buf][s_][i_], re[buf][s_], BJ[i_]);                     \
+  }
+      int m = mJ, slot = bJ;
+      int kA = -1, kB = -1;
+      if (m) {
+        kA = __builtin_ctz(m);
+        m &= m - 1;
+        HGP_CFILL(0, kA, slot)
+        ++slot;
+      }
+#pragma nounroll
+      while (kA >= 0) {
+        kB = -1;
+        if (m) {
+          kB = __builtin_ctz(m);
+          m &= m - 1;
+          HGP_CFILL(1, kB, slot)
+          ++slot;
+        }
+        HGP_CMMA(0)
+        if (kB < 0) break;
+        kA = -1;
+        if (m) {
+          kA = __builtin_ctz(m);
+          m &= m - 1;
+          HGP_CFILL(0, kA, slot)
+          ++slot;
+        }
+        HGP_CMMA(1)
+      }
+      HGP_ACC(3);
+      // sweep 2: U[I][J] += E[Kt, I]^T BJ[i] over the active blocks (Kt = 4h + i, I <= J) of E.  Per tile the operands
+      // of all its active blocks in this chunk are requested first, then multiplied: one LDS latency per tile.
+#pragma unroll
+      for (int I = 0; I < 4 * q + 4; ++I) {
+        const int m4 = (msk[I] >> (CH * h)) & nb4;
+        if (I <= J && m4) {
+          const int below = __popc(msk[I] & ((1 << (CH * h)) - 1));
+          double af[CH][4];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            if (m4 & (1 << i)) {
+              const int slot2 = bas[I] + below + __popc(m4 & ((1 << i) - 1));
+#pragma unroll
+              for (int s = 0; s < 4; ++s) af[i][s] = e_op(slot2, s);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            if (m4 & (1 << i)) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s) U[C::loc(I, q)] = mfma(af[i][s], BJ[i][s], U[C::loc(I, q)]);
+            }
+          }
+        }
+      }
+      HGP_ACC(4);
+    }
+  }
+#undef HGP_CFILL
+#undef HGP_CMMA
+
+  // regularisation of the reference: +1e-6 I (GPI.py:501), + first, + 1e-8 mean|diag| I (GPI_model.py:83-87)
+  {
+    const double sh = 1e-6 + fn;
+    const double dm = coop_diag_abs_mean<NB>(U, Ts, wave, lane, sh, red);   // (also orders the dvec writes: barrier)
+    coop_add_diag<NB>(U, sh + 1e-8 * fmax(dm, F64_EPS), Ts, wave, lane);
+  }
+  PivotAcc pa;
+  pa.init();
+  HGP_ACC(5);
+  double zq = coop_factor<NB, 2>(U, rowbuf, nullptr, Wbuf, scr, wave, lane, pa, nullptr, 0, Ts, dvec);
+  int info;
+  const double ld = coop_logdet_info(pa, wave, lane, red, redi, info);
+  zq = wave_sum(zq);
+  if (lane == 0) red[8 + wave] = zq;
+  __syncthreads();
+  if (tid == 0) {
+    a.out_quad[oidx] = red[8] + red[9] + red[10] + red[11];
+    if (a.out_logdet) a.out_logdet[oidx] = ld;
+    if (a.out_info) a.out_info[oidx] = info;
+  }
+  release_area();
+  HGP_ACC(6);
+#ifdef HGP_STAMPS
+  if (tid == 64 * (WAVES - 1) && a.stamps) {   // the view of the last wave
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
+    for (int i = 0; i < 5; ++i) atomicAdd(&a.stamps[8 + i], pa.cf[i]);
+  }
+#endif
+}
+
+// The same pipeline with NB/2 waves per pair (CoopH<NB>, tile_f64.hpp: 8 waves and 17 tiles per wave at NB = 16 instead
+// of 4 waves and 34-40 tiles): more than one wave per SIMD, so the latencies and barrier waits of one wave sit under the
+// MFMAs of another.
+template <int NB>
+__global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs_cooph(PairsArgs a) {
+  using PC = PairsCoop<NB>;
+  using H = CoopH<NB>;
+  constexpr int NW = H::NW;
+  constexpr int TP = 16 * NB, CAP = PC::CAP;
+  constexpr int CH = (NB <= 8 && NB % 4 == 0) ? 4 : 2;   // row tiles of B[:, J] per pass (must divide NB; register budget)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ec = smem;                    // [CAP][4][64]
+  double* rowbuf = Ec + CAP * 256;      // [NB][4][64]
+  double* Wbuf = rowbuf + NB * 256;
+  double* dvec = Wbuf + 256;            // d, then z = L^{-1} d
+  double* xs = dvec + TP;
+  double* ys = xs + TP;
+  double* xbs = ys + TP;
+  double* scr = xbs + TP;
+  double* red = scr + DIAG_SCR;         // 16 doubles
+  int* redi = reinterpret_cast<int*>(red + 16);   // 8
+  int* amask = redi + 8;                // bit Kt of amask[J]: block (Kt, J) of E active
+  int* kmask = amask + 16;              // bit I of kmask[J]: tile (I, J) of K** above the cut-off (I <= J)
+  int* pneed = kmask + 16;              // OR of amask[0..J]: row tiles of B[:, J] that sweep 2 reads
+  int* base = pneed + 16;               // first slot of column J (prefix sum of popcounts), base[NB] = total
+  int* slotblk = base + 20;             // slot -> (Kt << 8) | J
+  double* rng = reinterpret_cast<double*>(slotblk + NB * NB);   // [2 NB][lo, hi] of the real points of each 16-block
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.T, Ts = a.Ts;
+  const int Kg = a.kend - a.kbeg;
+
+  // block -> (segment, cluster).  Without `sel` the Kg clusters of the group are spread over the 8 XCDs (block b runs
+  // on XCD b % 8) so that each XCD's L2 keeps the operators of Kg / 8 clusters only.
+  int n, kc;
+  if (a.sel) {
+    n = blockIdx.x;
+    kc = a.sel[n];
+    bool mine = false;
+    for (int kk = a.kbeg; kk < a.kend; ++kk) mine = mine || (a.perm[kk] == kc);
+    if (!mine) return;
+  } else {
+    const int b = blockIdx.x;
+    int kk;
+    if ((Kg & 7) == 0) {
+      const int cpx = Kg >> 3, s = b >> 3;
+      kk = (b & 7) + 8 * (s % cpx);
+      n = s / cpx;
+    } else {
+      kk = b % Kg;
+      n = b / Kg;
+    }
+    kc = a.perm[a.kbeg + kk];
+  }
+  if (a.scal[8 * kc + 7] != 0.0) return;   // ill-conditioned K~: scored by the solve-based kernel (hgp_pairs_acc.hip)
+
+  HGP_STAMP_DECL
+  HGP_T0();
+  for (int i = tid; i < TP; i += 64 * NW) {   // sentinel padding as in k_pairs
+    xs[i] = (i < Ts) ? a.x[(size_t)n * Ts + i] / a.ell : 1e150 * (double)(1 + i);
+    ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
+    xbs[i] = (i < T) ? a.xb[i] / a.ell : -1e150 * (double)(1 + i);
+  }
+  if (tid < 16) {
+    amask[tid] = 0;
+    kmask[tid] = 0;
+  }
+  __syncthreads();
+  // Which 16x16 blocks of E (and tiles of K**) can hold an entry above the cut-off?  Decided from the data: the
+  // range [min, max] of the REAL points of every 16-block (padding excluded), then block (Kt, J) is active iff the
+  // two ranges are closer than the cut-off radius.  Exact for sorted grids, a superset otherwise (never drops a block).
+  for (int b16 = wave; b16 < 2 * NB; b16 += NW) {
+    const int B = (b16 < NB) ? b16 : b16 - NB;
+    const int i = 16 * B + c;
+    const bool real = (b16 < NB) ? (i < T) : (i < Ts);
+    const double v = (b16 < NB) ? xbs[i] : xs[i];
+    double lo = real ? v : __builtin_inf(), hi = real ? v : -__builtin_inf();
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+      lo = fmin(lo, __shfl_xor(lo, o, 64));
+      hi = fmax(hi, __shfl_xor(hi, o, 64));
+    }
+    if (lane == 0) {
+      rng[2 * b16] = lo;
+      rng[2 * b16 + 1] = hi;
+    }
+  }
+  __syncthreads();
+  bool actE = false;
+  int myKt = 0, myJb = 0;
+  if (tid < NB * NB) {
+    myKt = tid / NB;
+    myJb = tid % NB;
+    const double xlo = rng[2 * (NB + myJb)], xhi = rng[2 * (NB + myJb) + 1];
+    const double gE = fmax(0.0, fmax(rng[2 * myKt] - xhi, xlo - rng[2 * myKt + 1]));
+    actE = 0.5 * (gE * gE) < PAIRS_CUT;
+    if (actE) atomicOr(&amask[myJb], 1 << myKt);
+    if (myKt <= myJb) {
+      const double gK = fmax(0.0, fmax(rng[2 * (NB + myKt)] - xhi, xlo - rng[2 * (NB + myKt) + 1]));
+      if (0.5 * (gK * gK) < PAIRS_CUT) atomicOr(&kmask[myJb], 1 << myKt);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int s = 0, o = 0;
+    for (int J = 0; J < NB; ++J) {
+      base[J] = s;
+      s += __popc(amask[J]);
+      o |= amask[J];
+      pneed[J] = o;
+    }
+    base[NB] = s;
+  }
+  __syncthreads();
+  if (actE) slotblk[base[myJb] + __popc(amask[myJb] & ((1 << myKt) - 1))] = (myKt << 8) | myJb;
+  const int nslot = __builtin_amdgcn_readfirstlane(base[NB]);
+  // Dense grids: the blocks beyond the LDS slots go to a global scratch area of this workgroup.  Areas are handed out
+  // with a compare-and-swap on a flag array that has more entries than workgroups can be resident at once.
+  double* Eov = nullptr;
+  int my_area = -1;
+  if (nslot > CAP) {
+    if (tid == 0) {
+      int sidx = blockIdx.x % a.nscr;
+      while (atomicCAS(&a.eflags[sidx], 0, 1) != 0) sidx = (sidx + 1 == a.nscr) ? 0 : sidx + 1;
+      redi[7] = sidx;
+    }
+    __syncthreads();
+    my_area = redi[7];
+    Eov = a.escr + (size_t)my_area * a.escr_stride;
+  }
+  __syncthreads();
+  for (int slot = wave; slot < nslot; slot += NW) {
+    const int kj = __builtin_amdgcn_readfirstlane(slotblk[slot]);
+    const int Kt = kj >> 8, Jb = kj & 255;
+    double* dst = (slot < CAP) ? Ec + slot * 256 : Eov + (size_t)(slot - CAP) * 256;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double u = xbs[16 * Kt + 4 * s + g] - xs[16 * Jb + c];
+      dst[s * 64 + lane] = exp(-0.5 * (u * u));
+    }
+  }
+  __syncthreads();
+  // E[16 Kt + 4 s + g][16 Jb + c] of the block in `slot`: the B operand of sweep 1 (k-step s) and the A operand of sweep 2
+  // (the overflow read is a volatile global load on purpose: with two plain loads the compiler merges the branches
+  //  into ONE flat_load through a selected generic pointer, which costs the LDS path its ds_read and its wait counter)
+  auto e_op = [&](int slot, int s) -> double {
+    if (slot < CAP) return Ec[slot * 256 + s * 64 + lane];
+    return *reinterpret_cast<const volatile double*>(Eov + (size_t)(slot - CAP) * 256 + s * 64 + lane);
+  };
+  auto release_area = [&]() {
+    if (my_area >= 0) {
+      __syncthreads();
+      if (tid == 0) {
+        __threadfence();
+        atomicExch(&a.eflags[my_area], 0);
+      }
+    }
+  };
+
+  HGP_ACC(0);
+  const double* sc = a.scal + 8 * kc;
+  const double cc = sc[0], noise = sc[2];
+  const bool iso = sc[3] != 0.0;
+  const size_t oidx = a.sel ? (size_t)n : (size_t)n * a.K + kc;
+  const double fn = a.first_noise ? a.first_noise[oidx] : 0.0;
+
+  // d = y - E^T a'  (block columns dealt to the waves)
+  const double* apk = a.ap + (size_t)kc * TP;
+  double dsq = 0.0;
+  for (int Jb = wave; Jb < NB; Jb += NW) {
+    int m = __builtin_amdgcn_readfirstlane(amask[Jb]);
+    int slot = __builtin_amdgcn_readfirstlane(base[Jb]);
+    double p = 0.0;
+    while (m) {
+      const int Kt = __builtin_ctz(m);
+      m &= m - 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) p = fma(e_op(slot, s), apk[16 * Kt + 4 * s + g], p);
+      ++slot;
+    }
+    p = xrow_sum(p);
+    if (g == 0) {
+      const int j = 16 * Jb + c;
+      const double d = ys[j] - p;
+      dvec[j] = d;
+      dsq = fma(d, d, dsq);
+    }
+  }
+  HGP_ACC(1);
+  if (iso) {   // GPI.py:497-498: cov_f = mean(diag Sigma) I
+    dsq = wave_sum(dsq);
+    if (lane == 0) red[wave] = dsq;
+    __syncthreads();
+    if (tid == 0) {
+      const double v = sc[4] + fn;
+      const double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
+      double tot_ = 0.0;
+      for (int w_ = 0; w_ < NW; ++w_) tot_ += red[w_];
+      a.out_quad[oidx] = tot_ / v2;
+      if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
+      if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
+    }
+    release_area();
+    return;
+  }
+
+  int msk[NB], bas[NB];   // uniform copies for the statically indexed uses of sweep 2
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    msk[I] = __builtin_amdgcn_readfirstlane(amask[I]);
+    bas[I] = __builtin_amdgcn_readfirstlane(base[I]);
+  }
+  const double* Mk = a.Mp + (size_t)kc * TP * TP;   // plain row-major here (no tile-pair interleave)
+  d4 U[H::NT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int J = (q == 0) ? wave : NB - 1 - wave;   // my block columns: A (rows 0..wave) and B (rows 0..NB-1-wave)
+    const int mJ = __builtin_amdgcn_readfirstlane(amask[J]), bJ = __builtin_amdgcn_readfirstlane(base[J]);
+    const int kmJ = __builtin_amdgcn_readfirstlane(kmask[J]), need = __builtin_amdgcn_readfirstlane(pneed[J]);
+    // K** = c exp(-0.5 (x_i - x_j)^2) + noise I on my column (the one-argument kernel call, GPI.py:476)
+#pragma unroll
+    for (int I = 0; I < (q == 0 ? NW : NB); ++I) {
+      const int ln = launder(lane);
+      d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
+      if (I <= J) {
+        if (kmJ & (1 << I)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
+            kt[r] = cc * exp(-0.5 * (u * u));
+          }
+        }
+        if (I == J) {   // exact diagonal; identity on the padding
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((ln >> 4) + 4 * r == (ln & 15)) kt[r] = (16 * I + (ln & 15) < Ts) ? cc + noise : 1.0;
+        }
+      }
+      if (I <= J) U[q == 0 ? H::slotA(I) : H::slotB(I)] = kt;   // (slots of rows I > J belong to the other column)
+    }
+    HGP_ACC(2);
+#pragma nounroll
+    for (int h = 0; h < NB / CH; ++h) {
+      const int nb4 = (need >> (CH * h)) & ((1 << CH) - 1);
+      if (!nb4) continue;
+      // sweep 1: BJ[i] = M'[rows of tile 4h + i, :] E[:, J] over the active blocks of column J.  M' is symmetric:
+      // the A operand of output row tile i, k-step s of block Kt is M'[16 Kt + 4 s + g][16 (4h + i) + c] (coalesced).
+      d4 BJ[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) BJ[i] = (d4){0.0, 0.0, 0.0, 0.0};
+      const double* Mh = Mk + (size_t)g * TP + 16 * CH * h + c;
+      double ra[2][4][CH], re[2][4];
+#define HGP_CFILL(buf, Kt_, slot_)                                                                  \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
+    const double* row_ = Mh + (size_t)(16 * (Kt_) + 4 * s_) * TP;                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) ra[buf][s_][i_] = row_[16 * i_];               \
+    re[buf][s_] = e_op((slot_), s_);                                                                 \
+  }
+#define HGP_CMMA(buf)                                                                               \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_)                                               \
+      if (nb4 & (1 << i_)) BJ[i_] = mfma(ra[buf][s_][i_], re[buf][s_], BJ[i_]);                     \
+  }
+      int m = mJ, slot = bJ;
+      int kA = -1, kB = -1;
+      if (m) {
+        kA = __builtin_ctz(m);
+        m &= m - 1;
+        HGP_CFILL(0, kA, slot)
+        ++slot;
+      }
+#pragma nounroll
+      while (kA >= 0) {
+        kB = -1;
+        if (m) {
+          kB = __builtin_ctz(m);
+          m &= m - 1;
+          HGP_CFILL(1, kB, slot)
+          ++slot;
+        }
+        HGP_CMMA(0)
+        if (kB < 0) break;
+        kA = -1;
+        if (m) {
+          kA = __builtin_ctz(m);
+          m &= m - 1;
+          HGP_CFILL(0, kA, slot)
+          ++slot;
+        }
+        HGP_CMMA(1)
+      }
+      HGP_ACC(3);
+      // sweep 2: U[I][J] += E[Kt, I]^T BJ[i] over the active blocks (Kt = 4h + i, I <= J) of E.  Per tile the operands
+      // of all its active blocks in this chunk are requested first, then multiplied: one LDS latency per tile.
+#pragma unroll
+      for (int I = 0; I < (q == 0 ? NW : NB); ++I) {
+        const int m4 = (msk[I] >> (CH * h)) & nb4;
+        if (I <= J && m4) {
+          const int below = __popc(msk[I] & ((1 << (CH * h)) - 1));
+          double af[CH][4];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            if (m4 & (1 << i)) {
+              const int slot2 = bas[I] + below + __popc(m4 & ((1 << i) - 1));
+#pragma unroll
+              for (int s = 0; s < 4; ++s) af[i][s] = e_op(slot2, s);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            if (m4 & (1 << i)) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s) U[q == 0 ? H::slotA(I) : H::slotB(I)] = mfma(af[i][s], BJ[i][s], U[q == 0 ? H::slotA(I) : H::slotB(I)]);
+            }
+          }
+        }
+      }
+      HGP_ACC(4);
+    }
+  }
+#undef HGP_CFILL
+#undef HGP_CMMA
+
+  // regularisation of the reference: +1e-6 I (GPI.py:501), + first, + 1e-8 mean|diag| I (GPI_model.py:83-87)
+  {
+    const double sh = 1e-6 + fn;
+    const double dm = cooph_diag_abs_mean<NB>(U, Ts, wave, lane, sh, red);   // (also orders the dvec writes: barrier)
+    cooph_add_diag<NB>(U, sh + 1e-8 * fmax(dm, F64_EPS), Ts, wave, lane);
+  }
+  PivotAcc pa;
+  pa.init();
+  HGP_ACC(5);
+  double zq = cooph_factor<NB>(U, rowbuf, Wbuf, scr, wave, lane, pa, Ts, dvec);
+  int info;
+  const double ld = cooph_logdet_info<NB>(pa, wave, lane, red, redi, info);
+  zq = wave_sum(zq);
+  if (lane == 0) red[8 + wave] = zq;
+  __syncthreads();
+  if (tid == 0) {
+    double tot_ = 0.0;
+    for (int w_ = 0; w_ < NW; ++w_) tot_ += red[8 + w_];
+    a.out_quad[oidx] = tot_;
+    if (a.out_logdet) a.out_logdet[oidx] = ld;
+    if (a.out_info) a.out_info[oidx] = info;
+  }
+  release_area();
+  HGP_ACC(6);
+#ifdef HGP_STAMPS
+  if (tid == 64 * (WAVES - 1) && a.stamps) {   // the view of the last wave
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
+  }
+#endif
+}
+
+template <int NB>
+int launch_pairs_cooph(const PairsArgs& a, hipStream_t st) {
+  const size_t lds = PairsCoop<NB>::LDS_BYTES;
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs_cooph<NB>), lds)) return rc_;
+  const int blocks = a.sel ? a.N : a.N * (a.kend - a.kbeg);
+  hipLaunchKernelGGL(k_pairs_cooph<NB>, dim3(blocks), dim3(64 * CoopH<NB>::NW), lds, st, a);
+  return launch_status();
+}
+
+template <int NB>
+int launch_pairs_coop(const PairsArgs& a, hipStream_t st) {
+  const size_t lds = PairsCoop<NB>::LDS_BYTES;
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs_coop<NB>), lds)) return rc_;
+  const int blocks = a.sel ? a.N : a.N * (a.kend - a.kbeg);
+  hipLaunchKernelGGL(k_pairs_coop<NB>, dim3(blocks), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
+template <int NB>
+int launch_pairs(const PairsArgs& a, hipStream_t st) {
+  size_t lds = pairs_lds_bytes<NB>();
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs<NB>), lds)) return rc_;
+  hipLaunchKernelGGL(k_pairs<NB>, dim3(a.N), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
+}  // namespace
+
+// dispatch by padded size / kernel family (see hgp_loglik_pairs_f64)
+int hgp_internal_pairs_fast(const PairsArgs& a, int NB, bool coop, bool four_wave, hipStream_t st) {
+  if (coop) {   // NB/2 waves per pair (CoopH); four_wave (HGP_PAIRS_COOP4=1) selects the 4-wave kernels (Coop) for comparison
+    switch (NB) {
+      case 4: return launch_pairs_coop<4>(a, st);
+      case 8: return four_wave ? launch_pairs_coop<8>(a, st) : launch_pairs_cooph<8>(a, st);
+      case 12: return four_wave ? launch_pairs_coop<12>(a, st) : launch_pairs_cooph<12>(a, st);
+      default: return four_wave ? launch_pairs_coop<16>(a, st) : launch_pairs_cooph<16>(a, st);
+    }
+  }
+  switch (NB) {
+    case 2: return launch_pairs<2>(a, st);
+    case 4: return launch_pairs<4>(a, st);
+    case 6: return launch_pairs<6>(a, st);
+    default: return launch_pairs<8>(a, st);
+  }
+}
