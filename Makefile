@@ -35,5 +35,15 @@ racestress: $(SRCS) $(HDR)
 	mkdir -p build/probe
 	$(HIPCC) $(FLAGS) -DHGP_RACE_STRESS -shared -o build/probe/libhgp_race_stress.so $(SRCS)
 
+# in-situ knock-out builds of k_pairs (results wrong by construction, only the time matters; tools/knockout_time.py):
+# one component replaced by a stub each - what the component costs INSIDE the kernel, not in isolation
+KNOCKOUTS = NOEXP NODIAG NORHS NOFACTOR NOFILL NOAF SHARED_M
+knockouts: $(LIB)
+	mkdir -p build/probe
+	for v in $(KNOCKOUTS); do \
+	  $(HIPCC) $(FLAGS) -DHGP_EXP_$$v -c -o build/probe/hgp_pairs_$$v.o $(CSRC)/hgp_pairs.hip && \
+	  $(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/probe/libhgp_exp_$$v.so $(filter-out $(OBJDIR)/hgp_pairs.o,$(OBJS)) build/probe/hgp_pairs_$$v.o || exit 1; \
+	done
+
 clean:
 	rm -rf $(LIB) $(OBJDIR)

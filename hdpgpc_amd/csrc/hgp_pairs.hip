@@ -12,6 +12,13 @@
 
 using namespace hgp;
 
+// in-situ knock-out experiments (diagnostic builds only; results are wrong by construction)
+#ifdef HGP_EXP_NOEXP
+#define HGP_EXPF(x) (1.0 / (1.0 - (x)))
+#else
+#define HGP_EXPF(x) exp(x)
+#endif
+
 namespace {
 
 // -------------------------------------------------------------------------------------- a2 + a5
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
       }
       if (__any(near)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) E[(16 * Kt + g + 4 * r) * TP + j] = exp(-h[r]);
+        for (int r = 0; r < 4; ++r) E[(16 * Kt + g + 4 * r) * TP + j] = HGP_EXPF(-h[r]);
         if (lane == 0) atomicOr(&amask[Jb], 1 << Kt);
       }
     }
@@ -155,12 +162,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     d4 cov[NB * (NB + 1) / 2];
     // cov[I][J] += sum_h E[rows h, I]^T (M'[rows h, :] E[:, J]) : the basis index is split in two halves
     // so the intermediate panel is 4 tiles; it feeds the second sweep straight from its accumulators.
+#ifdef HGP_EXP_SHARED_M   // experiment: every wave of the chip streams the SAME M' (wrong results; upper bound of M' locality)
+    const double* Mbase = a.Mp + (size_t)g * TP;
+#else
     const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP;   // + column offset inside HGP_FILL (interleaved)
+#endif
     // Sweep-1 operand ring: 4 slots of half a k-block each (2 k-steps: 2 x NH rows of M' from L2 + 2 values of E
     // from LDS).  A slot is refilled right after its MFMAs are issued, i.e. three half-blocks (about 1.5k cycles
     // of MFMA) before it is used again; the first two blocks of the NEXT sweep are requested at the end of a sweep.
     double ra[4][2][NH], re[4][2];
     int kA = -1, kB = -1, m = msk[0];
+#ifdef HGP_EXP_NOFILL   // knock-out: sweep-1 operands are constants (no global loads, no LDS reads, no address arithmetic)
+#define HGP_FILL(slot, half, blk, Mptr, Jcol)                                                               \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                        \
+    _Pragma("unroll") for (int P_ = 0; P_ < NH; ++P_) ra[slot][s_][P_] = 1e-3 * (double)(blk);              \
+    re[slot][s_] = 1e-3 * (double)(Jcol);                                                                   \
+  }
+#else
 #define HGP_FILL(slot, half, blk, Mptr, Jcol)                                                               \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                        \
     const double* row_ = (Mptr) + (size_t)(16 * (blk) + 4 * (2 * (half) + s_)) * TP;                        \
@@ -172,6 +190,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     if (NH & 1) ra[slot][s_][NH - 1] = row_[16 * (NH - 1) + c];                                             \
     re[slot][s_] = E[(16 * (blk) + 4 * (2 * (half) + s_) + g) * TP + 16 * (Jcol) + c];                      \
   }
+#endif
 #define HGP_MMA(slot)                                                                                       \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                        \
     _Pragma("unroll") for (int I_ = 0; I_ < NH; ++I_) BJ[I_] = mfma(ra[slot][s_][I_], re[slot][s_], BJ[I_]); \
@@ -254,7 +273,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
-                kt[r] = cc * exp(-0.5 * (u * u));
+                kt[r] = cc * HGP_EXPF(-0.5 * (u * u));
               }
             }
             if (I == J) {   // exact diagonal of the one-argument kernel call; identity on the padding
@@ -276,7 +295,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             // the reads can then be issued ahead of the branch and overlap the previous block's MFMAs
             double af[4];
 #pragma unroll
+#ifdef HGP_EXP_NOAF   // knock-out: sweep-2 A operands are constants (no LDS reads, no address arithmetic)
+            for (int r = 0; r < 4; ++r) af[r] = 1e-3 * (double)(Kt + I + r);
+#else
             for (int r = 0; r < 4; ++r) af[r] = E[(16 * (NH * h + Kt) + 4 * r + g) * TP + 16 * I + c];
+#endif
             if (msk[I] & (1 << (NH * h + Kt))) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) cov[tix(I, J, NB)] = mfma(af[r], BJ[Kt][r], cov[tix(I, J, NB)]);
@@ -297,7 +320,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     pa.init();
     d4 Rnone[NB];
     HGP_ACC(4);
+#ifdef HGP_EXP_NORHS   // knock-out: factor only, no right-hand side (diagnostic builds only)
+    wave_factor<NB, 0, (NB >= 8)>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
+    const double q = dv[lane];
+#elif defined(HGP_EXP_NOFACTOR)   // knock-out: no factorisation at all
+    double q = dv[lane];
+#pragma unroll
+    for (int i_ = 0; i_ < NB * (NB + 1) / 2; ++i_) q += cov[i_][0] + cov[i_][1] + cov[i_][2] + cov[i_][3];
+#else
     const double q = wave_factor<NB, 2, (NB >= 8)>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
+#endif
     if (lane == 0) {
       a.out_quad[oidx] = q;
       if (a.out_logdet) a.out_logdet[oidx] = pa.logdet();

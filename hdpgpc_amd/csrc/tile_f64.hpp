@@ -174,6 +174,15 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 __device__ __forceinline__ d4 diag16(const d4& Xin, double* scr, int lane, PivotAcc& pa, int col0,
                                      double* Lout, int ldl, int nvalid) {
   const int g = lane >> 4, c = lane & 15;
+#ifdef HGP_EXP_NODIAG   // in-situ knock-out experiment (diagnostic builds only): W = diag(1 / sqrt(x_ii)), no pivot chain
+  {
+    d4 w;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = (4 * s + g == c) ? 1.0 / sqrt(fabs(Xin[s]) + 1.0) : 0.0;
+    pa.mant *= 1.0 + 1e-300 * Xin[0];
+    return w;
+  }
+#endif
 #ifdef HGP_STAMPS
   const unsigned long long td0 = __builtin_readcyclecounter();
 #endif
@@ -259,6 +268,15 @@ __device__ __forceinline__ d4 diag16(const d4& Xin, double* scr, int lane, Pivot
 __device__ __forceinline__ d4 diag16_valu(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
                                      double* Lout, int ldl, int nvalid) {
   const int g = lane >> 4, c = lane & 15;
+#ifdef HGP_EXP_NODIAG   // in-situ knock-out experiment (diagnostic builds only)
+  {
+    d4 w;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = (4 * s + g == c) ? 1.0 / sqrt(fabs(X[s]) + 1.0) : 0.0;
+    pa.mant *= 1.0 + 1e-300 * X[0];
+    return w;
+  }
+#endif
 #ifdef HGP_STAMPS
   const unsigned long long td0 = __builtin_readcyclecounter();
 #endif
