@@ -12,6 +12,9 @@
 
 using namespace hgp;
 
+#ifndef HGP_PAIRS_DIAG_MFMA
+#define HGP_PAIRS_DIAG_MFMA 1   // the MFMA-blocked diag16 also at NB = 8: 43 spilled VGPRs, still 1.5 % faster than diag16_valu (0 = the VALU form)
+#endif
 // in-situ knock-out experiments (diagnostic builds only; results are wrong by construction)
 #ifdef HGP_EXP_NOEXP
 #define HGP_EXPF(x) (1.0 / (1.0 - (x)))
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #pragma unroll
     for (int i_ = 0; i_ < NB * (NB + 1) / 2; ++i_) q += cov[i_][0] + cov[i_][1] + cov[i_][2] + cov[i_][3];
 #else
-    const double q = wave_factor<NB, 2, (NB >= 8)>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
+    const double q = wave_factor<NB, 2, (NB >= 8) && !HGP_PAIRS_DIAG_MFMA>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
 #endif
     if (lane == 0) {
       a.out_quad[oidx] = q;
