@@ -13,7 +13,7 @@
 using namespace hgp;
 
 #ifndef HGP_PAIRS_DIAG_MFMA
-#define HGP_PAIRS_DIAG_MFMA 1   // the MFMA-blocked diag16 also at NB = 8: 43 spilled VGPRs, still 1.5 % faster than diag16_valu (0 = the VALU form)
+#define HGP_PAIRS_DIAG_MFMA 0   // 1 = the MFMA-blocked diag16 also at NB = 8: measured 1.5 % faster, but 43 spilled VGPRs turn into 59 MB of scratch writes per launch (WRITE_SIZE): not kept
 #endif
 // in-situ knock-out experiments (diagnostic builds only; results are wrong by construction)
 #ifdef HGP_EXP_NOEXP
