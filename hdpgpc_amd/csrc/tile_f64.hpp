@@ -268,6 +268,12 @@ __device__ __forceinline__ d4 diag16(const d4& Xin, double* scr, int lane, Pivot
 // The all-VALU form of the same block (column j of U in lane j, column j of Z = L^{-1} in lane 16 + j, 16 elimination
 // steps of 15 v_readlane + 15 v_fma): the same ~4.2k cycles in isolation (tools/probe_diag16.hip) with ~20 fewer live
 // registers, which is what the T = 128 single-matrix kernel (k_wave_score1<8>, 36 resident tiles) needs to avoid spills.
+// Round 2 measured two rewrites of the elimination loop, both correct, neither faster (isolation 4.19 / 4.38 k cycles against
+// 4.27 k; inside k_pairs<8> 1.548 / 1.573 ms against 1.535 ms) and both removed: (a) the multiplier broadcast inside the
+// FMA (v_fmac_f64_dpp row_newbcast, the pivot row copied into row 1 of the wave by v_permlane16_swap): one instruction per
+// element instead of two v_readlane_b32 + one v_fma_f64, 35 % fewer instructions; (b) on top of it the division-free
+// (Bareiss) form with the sixteen 1/sqrt taken after the loop, one per lane.  The block costs ~260 cycles per pivot whatever
+// sits on the chain: a dependent fp64 VALU instruction issues ~25 cycles after its producer at one wave per SIMD.
 __device__ __forceinline__ d4 diag16_valu(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
                                      double* Lout, int ldl, int nvalid) {
   const int g = lane >> 4, c = lane & 15;
