@@ -212,10 +212,12 @@ def test_pairs_accuracy_bound_tracks_conditioning():
     assert rel_err(quad.cpu().numpy(), q_ref) < RT_PAIR
 
 
-def test_pairs_block_skipping_on_arbitrary_grids():
-    """The kernel drops 16x16 blocks of the cross-Gram whose entries are all < 1e-36; the decision is taken
-    from the data, so shifted, reversed, permuted and far-away grids must all agree with the oracle."""
-    T, K = 64, 3
+@pytest.mark.parametrize("T", [64, 90, 128])
+def test_pairs_block_skipping_on_arbitrary_grids(T):
+    """The kernel drops 16x16 blocks of the cross-Gram whose entries are all < 1e-36, and whole half-sweeps whose rows of
+    M'E no active block reads; both decisions are taken from the data, so shifted, reversed, permuted and far-away grids
+    must all agree with the oracle."""
+    K = 3
     b = orc.synthetic_batch(6, K, T, seed=31)
     rng = np.random.default_rng(3)
     x = b["x"].copy()
@@ -224,6 +226,7 @@ def test_pairs_block_skipping_on_arbitrary_grids():
     x[3] = rng.permutation(x[3])            # permuted: no band structure at all
     x[4] = x[4] + 500.0                     # far away: every block of E inactive (cov = K** only)
     x[5] = np.linspace(10.0, 20.0, T)       # dense cluster of points: few wide active blocks
+    x[0] = np.concatenate((x[0][T // 2:], x[0][:T // 2]))     # halves swapped: the early panels need the LOWER rows of M'E
     plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
     quad, logdet, info = plan.loglik(dev(x), dev(b["y"]))
     assert int(info.abs().max()) == 0
