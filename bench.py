@@ -309,6 +309,11 @@ def main():
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_shared_grid(dev, ops)
             res["secondary_large_T"] = secondary_large_T(dev, ops, synth)
+            # the WHOLE batch of configs[3] on this one GPU: the N = 1 point of the strong-scaling curve `--gpus N > 1` measures
+            # (there the headline line itself is configs[3], 32 768 / N rows per rank)
+            base = secondary_large_T(dev, ops, synth, N=32768, reps=2)
+            base["workload"] = "configs[3] whole batch on ONE GPU (strong-scaling base of --gpus N): " + base["workload"].split(": ", 1)[1]
+            res["strong_scaling_base"] = base
             res["secondary_rank1"] = secondary_rank1(dev, ops)
             res["secondary_matrix_terms"] = secondary_matrix_terms(dev, ops)
         if cpu is not None:
