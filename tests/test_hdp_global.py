@@ -1,0 +1,32 @@
+"""Host-side HDP pseudo-counts of the drop-in surface (hdpgpc_amd/hdp_global.py: the bnpy surrogate bound on (rho, omega),
+L-BFGS-B) against what the reference computed in reload_model_from_labels on MIT-BIH record 102
+(tests/golden/reload_r102.npz, reload_r102_2leads.npz): counts from the labels -> theta -> two rounds of optimisation.
+Pure NumPy / SciPy: runs without a GPU."""
+import numpy as np
+import pytest
+from scipy.special import digamma
+
+from conftest import golden
+
+
+@pytest.mark.parametrize("fixture", ["reload_r102.npz", "reload_r102_2leads.npz"])
+def test_rho_omega_and_theta_match_the_reference(fixture):
+    from hdpgpc_amd import hdp_global
+    g = golden(fixture)
+    lab, M = g["labels"], int(g["M"])
+    start = np.zeros(M)
+    start[lab[0]] = 1.0
+    trans = np.zeros((M, M))
+    np.add.at(trans, (lab[:-1], lab[1:]), 1.0)
+    from hdpgpc_amd.GPI_HDP import _HDP_HYP
+    gamma, trans_alpha, start_alpha, kappa = _HDP_HYP["balanced"]       # the constructor default (GPI_HDP.py:274-291)
+    rho = hdp_global.create_initrho(M)                                   # reinit_global_params, then two rounds (GPI_HDP.py:4006-4011)
+    omega = (1.0 + gamma) * np.ones(M)
+    for _ in range(2):
+        tt, st = hdp_global.calc_theta_full(trans, start, M + 1, rho, trans_alpha, start_alpha, kappa)
+        e_log_pi = digamma(tt) - np.log(np.sum(np.exp(digamma(tt)), axis=1) + 1e-5)[:, None]
+        s_log_pi = digamma(st) - np.log(np.sum(np.exp(digamma(st))) + 1e-5)
+        rho, omega, _ = hdp_global.find_optimum_rho_omega(np.sum(e_log_pi, axis=0), start_alpha * s_log_pi, M + 1, gamma,
+                                                          trans_alpha, kappa, rho, omega)
+    assert np.allclose(tt, g["transTheta"], rtol=1e-9) and np.allclose(st, g["startTheta"], rtol=1e-9)
+    assert np.allclose(rho, g["rho"], rtol=1e-9) and np.allclose(omega, g["omega"], rtol=1e-9)
