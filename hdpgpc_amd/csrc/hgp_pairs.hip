@@ -1074,6 +1074,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
 #ifdef HGP_STAMPS
   if (tid == 64 * (WAVES - 1) && a.stamps) {   // the view of the last wave
     for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
+    for (int i = 0; i < 5; ++i) atomicAdd(&a.stamps[8 + i], pa.cf[i]);
   }
 #endif
 }

@@ -979,6 +979,12 @@ __device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* r
   using C = CoopH<NB>;
   double zq = 0.0;
   const int JA = wave, JB = NB - 1 - wave;   // my block columns
+#ifdef HGP_STAMPS
+  unsigned long long cf_t = __builtin_readcyclecounter();
+#define HGP_CF(i) do { unsigned long long n_ = __builtin_readcyclecounter(); pa.cf[i] += n_ - cf_t; cf_t = n_; } while (0)
+#else
+#define HGP_CF(i)
+#endif
 #pragma unroll
   for (int K = 0; K < NB; ++K) {
     const int lane = launder(lane_in);
@@ -997,7 +1003,9 @@ __device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* r
         zq = fma(p, p, zq);
       }
     }
+    HGP_CF(0);
     __syncthreads();
+    HGP_CF(1);
     d4 W;
 #pragma unroll
     for (int s = 0; s < 4; ++s) W[s] = Wbuf[s * 64 + lane];
@@ -1024,7 +1032,9 @@ __device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* r
         if (g == 0) dvec[16 * J + c] -= tq;
       }
     }
+    HGP_CF(2);
     __syncthreads();
+    HGP_CF(3);
     // trailing: A_IJ -= U_KI^T U_KJ for my columns J >= I > K
     if (K + 1 < NB) {
       d4 ucur = lds_tile_load(rowbuf, K + 1, lane);
@@ -1043,10 +1053,12 @@ __device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* r
         ucur = unext;
       }
     }
+    HGP_CF(4);
   }
   __syncthreads();
   return zq;
 }
+#undef HGP_CF
 
 template <int NB>
 __device__ __forceinline__ double cooph_logdet_info(const PivotAcc& pa, int wave, int lane, double* red, int* redi, int& info) {
