@@ -734,7 +734,7 @@ class GPI_model:
         else:
             ta_all = torch.clamp_max(torch.arange(n - 1, device=self.device), nA - 1)
             Ab, Gb = A.index_select(0, ta_all), G.index_select(0, ta_all)
-        Pb = mm(mm(Ab, Cv[:n - 1]), Ab, transB=True) + Gb
+        Pb = mm(mm(Ab, Cv[:n - 1]), Ab, transB=True, add=Gb.contiguous())
         Zb, infob = ops.chol_inverse(Pb)
         self._pending.append(("backwards", infob))
         Jb = mm(mm(Cv[:n - 1], Ab, transB=True), mm(Zb, Zb, transA=True))
@@ -748,17 +748,23 @@ class GPI_model:
                 self.cov_f_sm[i + 1] = Cv[i]
             self._stk = {}
             return
-        t = torch.tensor([n - 2], dtype=torch.int64, device=self.device)
-
-        def step():
-            Jt, Pt = Jb.index_select(0, t)[0], Pb.index_select(0, t)[0]
-            mt, ct = M.index_select(0, t)[0], Cv.index_select(0, t)[0]
-            mn, cn = M.index_select(0, t + 1)[0], Cv.index_select(0, t + 1)[0]
-            M.index_copy_(0, t, (mt + mm(Jt, mn - AMb.index_select(0, t)[0])).unsqueeze(0))
-            Cv.index_copy_(0, t, (ct + mm(mm(Jt, cn - Pt), Jt, transB=True)).unsqueeze(0))
-            t.sub_(1)
-
-        self._run_graphed(step, M.shape[0] - 1)
+        # T > 96: the two-line recursion as product lists (hgp_gemm_list_f64), two dependent launches per step and no other
+        # arithmetic: what only reads filtered quantities is folded into addends first,
+        #     m_t <- J_t m_{t+1} + (m_t - J_t A_t m_t),      C_t <- (J_t C_{t+1} - J_t P_t) J_t^T + C_t.
+        self._check_pending()
+        T = M.shape[1]
+        JP = mm(Jb, Pb)
+        Mm = mm(Jb, AMb, alpha=-1.0, add=M[:n - 1].contiguous())
+        X = torch.empty((T, T), dtype=f64, device=self.device)
+        gl = ops.GemmList(self.device)
+        for t in range(n - 2, -1, -1):
+            gl.add(Jb[t], Cv[t + 1], X, D=JP[t], beta=-1.0)
+            gl.add(Jb[t], M[t + 1], M[t], D=Mm[t])
+            gl.add(X, Jb[t], Cv[t], D=Cv[t], transB=True)
+        gl.finalize()
+        for i in range(n - 1):
+            gl.run_range(3 * i, 2)
+            gl.run_range(3 * i + 2, 1)
         for i in range(M.shape[0]):
             self.f_star_sm[i + 1] = M[i]
             self.cov_f_sm[i + 1] = Cv[i]

@@ -398,7 +398,7 @@ class GemmList:
 
     def __init__(self, device):
         self.device = device
-        self._items, self._keep, self.tiles = [], [], 0
+        self._items, self._keep, self.tiles, self._item_tiles = [], [], 0, []
         self._dev = None
 
     @staticmethod
@@ -415,7 +415,7 @@ class GemmList:
         M, K = (ac, ar) if transA else (ar, ac)
         K2, N = (bc, br) if transB else (br, bc)
         orow, ocol, ldc = self._dims(out)
-        if K != K2 or (orow, ocol) != (M, N) or max(M, N, K) > 128:
+        if K != K2 or (orow, ocol) != (M, N) or max(M, N, K) > 256:
             raise ValueError(f"gemm list item {M}x{K} . {K2}x{N} -> {orow}x{ocol}")
         ldd = 0
         if D is not None:
@@ -432,7 +432,8 @@ class GemmList:
                            out2.data_ptr() if out2 is not None else None, M, N, K, lda, ldb, ldc, ldd, int(transA), int(transB),
                            float(alpha), float(beta), float(add_eye))
         self._items.append(it)
-        self.tiles += ((M + 15) // 16) * ((N + 15) // 16)
+        self._item_tiles.append(((M + 15) // 16) * ((N + 15) // 16))
+        self.tiles += self._item_tiles[-1]
         self._dev = None
         return out
 
@@ -447,6 +448,13 @@ class GemmList:
         if self._dev is None:
             self.finalize()
         _ffi.check(_ffi.lib.hgp_gemm_list_f64(_ptr(self._dev), len(self._items), self.tiles, _stream()), "gemm_list")
+
+    def run_range(self, first, count):
+        """One launch over the items [first, first + count) of the list (a long list holding the levels of many steps)."""
+        if self._dev is None:
+            self.finalize()
+        base = ctypes.c_void_p(self._dev.data_ptr() + first * ctypes.sizeof(_ffi.GemmItem))
+        _ffi.check(_ffi.lib.hgp_gemm_list_f64(base, int(count), sum(self._item_tiles[first:first + count]), _stream()), "gemm_list")
 
 
 def _dev64_any(t):

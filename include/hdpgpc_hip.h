@@ -210,7 +210,7 @@ int hgp_lds_chain_finish_f64(int T, const double* part, const double* ee, const 
                              void* stream);
 
 /* 8f-1, one launch per dependency level of the member step.  hgp_gemm_list_f64 executes a DEVICE-resident list of
- * heterogeneous products  C = alpha op(A) op(B) + beta D (+ add_eye on the diagonal), every dimension <= 128, vectors as N = 1;
+ * heterogeneous products  C = alpha op(A) op(B) + beta D (+ add_eye on the diagonal), any M x N x K, vectors as N = 1;
  * C2 (may be NULL) receives a second copy of the result.  total_tiles = sum over the items of ceil(M/16) ceil(N/16).
  * A step's lists are built once (every pointer is fixed for the life of a chain) and replayed from a hipGraph. */
 typedef struct hgp_gemm_item {

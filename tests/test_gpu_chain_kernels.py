@@ -16,7 +16,8 @@ def test_gemm_list_heterogeneous_items():
     rng = np.random.default_rng(5)
     gl = ops.GemmList("cuda")
     cases = []
-    shapes = [(90, 90, 90), (16, 16, 16), (17, 33, 5), (128, 128, 128), (1, 7, 100), (45, 1, 45), (100, 90, 3), (64, 1, 1)]
+    shapes = [(90, 90, 90), (16, 16, 16), (17, 33, 5), (128, 128, 128), (1, 7, 100), (45, 1, 45), (100, 90, 3), (64, 1, 1),
+              (256, 256, 256), (200, 1, 256), (144, 192, 130)]
     for idx, (M, N, K) in enumerate(shapes):
         tA, tB = bool(idx & 1), bool(idx & 2)
         A = rng.normal(size=(K, M) if tA else (M, K))
@@ -42,6 +43,7 @@ def test_gemm_list_heterogeneous_items():
         cases.append((out, out2, ref))
     gl.run()
     gl.run()                                            # a list is replayed (hipGraph): same result every time
+    gl.run_range(2, 3)                                  # a sub-range of the list is one launch too
     torch.cuda.synchronize()
     for out, out2, ref in cases:
         assert np.allclose(out.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
@@ -50,7 +52,7 @@ def test_gemm_list_heterogeneous_items():
     with pytest.raises(ValueError):
         gl.add(dev(np.zeros((4, 5))), dev(np.zeros((6, 4))), torch.zeros((4, 4), dtype=torch.float64, device="cuda"))
     with pytest.raises(ValueError):
-        gl.add(dev(np.zeros((129, 4))), dev(np.zeros((4, 4))), torch.zeros((129, 4), dtype=torch.float64, device="cuda"))
+        gl.add(dev(np.zeros((257, 4))), dev(np.zeros((4, 4))), torch.zeros((257, 4), dtype=torch.float64, device="cuda"))
 
 
 @pytest.mark.parametrize("T", [8, 33, 90, 128])
