@@ -589,8 +589,10 @@ class GPI_model:
         """The member step as ONE launch per dependency level (hgp_chain.hip): every product of the step is an item of a
         device-resident list whose pointers are fixed for the life of the chain; the two inversions carry their right-hand
         sides.  14 launches per member, no torch arithmetic, no allocation (measured: a dependent launch costs ~4.5 us
-        whatever it does, so launches - not flops - were the step's time)."""
+        whatever it does, so launches - not flops - were the step's time).  128 < T <= 256: the inversions are the
+        cooperative inverse-only kernels and Z rhs is one more list level behind each of them (16 launches)."""
         T = self.x_basis.shape[0]
+        riding = T <= 128
         tt = T * T
         dev = self.device
         new = lambda *shape: torch.zeros(shape, dtype=f64, device=dev)      # noqa: E731
@@ -641,9 +643,16 @@ class GPI_model:
         lv[9].add(Y3[0], Zs[0], part[0], transA=True)
         lv[9].add(Y3[1], Zs[1], part[1], transA=True)
         lv[9].add(X, J, P_sm_prev, D=c0, transB=True)
+        if not riding:
+            lvy = [ops.GemmList(dev), ops.GemmList(dev)]
+            lvy[0].add(Z4[0], RH4[0], Y4[0])                     # Z_P (A c0)
+            lvy[0].add(Z4[1], RH4[1], Y4[1])                     # Z_S (C P_k)
+            lvy[1].add(Zs[0], S_[0], Y3[0], transB=True)         # Z_s S_^T
+            lvy[1].add(Zs[1], S_[1], Y3[1], transB=True)
+            lv += lvy
         for l_ in lv:
             l_.finalize()
-        ch["lv"] = lv
+        ch["lv"], ch["riding"] = lv, riding
         ch["bufs"] = dict(X4=X4, RH4=RH4, Z4=Z4, Y4=Y4, S__=S__, S_=S_, Zs=Zs, Y3=Y3, part=part, y=y, f_post=f_post, c_post=c_post,
                           f_sm_prev=f_sm_prev, P_sm_prev=P_sm_prev)
         ch["rhs_on"] = torch.tensor([1, 1, 0, 0], dtype=torch.int32, device=dev)
@@ -657,10 +666,18 @@ class GPI_model:
                               ch["Y"], ch["y_row0"], b["y"], ch["W"], b["X4"][2:4])
         for i in range(4):
             lv[i].run()
-        ops.chol_inverse_rhs(b["X4"], b["Z4"], b["RH4"], b["Y4"], ch["i4"], rhs_on=ch["rhs_on"])
+        if ch["riding"]:
+            ops.chol_inverse_rhs(b["X4"], b["Z4"], b["RH4"], b["Y4"], ch["i4"], rhs_on=ch["rhs_on"])
+        else:
+            ops.chol_inverse(b["X4"], out=b["Z4"], info=ch["i4"])
+            lv[10].run()
         for i in range(4, 9):
             lv[i].run()
-        ops.chol_inverse_rhs(b["S__"], b["Zs"], b["S_"], b["Y3"], ch["i2"], rhs_trans=True, add_diag=1e-8)
+        if ch["riding"]:
+            ops.chol_inverse_rhs(b["S__"], b["Zs"], b["S_"], b["Y3"], ch["i2"], rhs_trans=True, add_diag=1e-8)
+        else:
+            ops.chol_inverse(b["S__"], 0.0, 1e-8, out=b["Zs"], info=ch["i2"])
+            lv[11].run()
         lv[9].run()
         ops.lds_chain_finish2(b["f_post"], b["c_post"], b["f_sm_prev"], b["P_sm_prev"], b["y"], b["part"], b["S__"], ch["i4"], ch["i2"],
                               ch["W"], ch["n0"], ch["Nf"], ch["bad"], ch["A"], ch["G"], ch["C"], ch["S"], ch["F"], ch["Fsm"], ch["P"],
@@ -796,10 +813,10 @@ class GPI_model:
             # observations of the run; the step reads row (pos - y_row0) inside its gather kernel
             ch["Y"] = (y_trains[rest][..., 0] if y_trains.ndim == 3 else y_trains[rest]).reshape(len(rest), -1).contiguous()
             ch["y_row0"] = int(ch["pos"][0])
-            if self.x_basis.shape[0] <= 128 and not ops.env_flag("HGP_CHAIN_PER_PRODUCT"):
+            if not ops.env_flag("HGP_CHAIN_PER_PRODUCT"):
                 self._chain_lists(ch)
                 self._run_graphed(lambda: self._chain_step2(ch), len(rest), unroll=8)
-            else:                                       # T > 128: one launch per product (workgroup-cooperative inverses)
+            else:                                       # round-1 form, one launch per product: kept for comparison
                 self._run_graphed(lambda: self._chain_step(ch), len(rest))
             self._chain_commit(ch, rest, x_trains, y_trains)
             bad = ch["bad"].tolist()

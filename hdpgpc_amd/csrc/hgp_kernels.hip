@@ -437,6 +437,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_inv(PotrfArgs a) {
       if (i < T && j < T) Z[(size_t)i * T + j] = (K >= Jc) ? z[r] : 0.0;
     }
   }
+  if (a.inv_info && Jc == 0) {   // inverse-only call: block column 0 saw every pivot
+    int info;
+    (void)coop_logdet_info(pa, wave, lane, red, reinterpret_cast<int*>(red + 8), info);
+    if (threadIdx.x == 0 && a.info) a.info[m] = info;
+  }
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once for every (kernel, device)
@@ -474,6 +479,14 @@ int launch_coop_potrf(const PotrfArgs& a, hipStream_t st) {
   if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_inv<NB>), lds)) return rc_;
   if (a.Linv) hipLaunchKernelGGL(k_coop_inv<NB>, dim3(a.b, NB), dim3(64 * WAVES), lds, st, a);
   hipLaunchKernelGGL(k_coop_potrf<NB>, dim3(a.b), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
+template <int NB>
+int launch_coop_inv_only(const PotrfArgs& a, hipStream_t st) {   // L^-1 without the in-place factor (A untouched)
+  const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_inv<NB>), lds)) return rc_;
+  hipLaunchKernelGGL(k_coop_inv<NB>, dim3(a.b, NB), dim3(64 * WAVES), lds, st, a);
   return launch_status();
 }
 
@@ -1919,10 +1932,11 @@ int hgp_chol_inverse_batched_f64(const double* A, int T, int b, double jitter_re
                                  int32_t* info, void* stream) {
   if (b == 0) return 0;
   if (!A || !Linv || T <= 0 || b < 0) return -1;
-  if (T > HGP_MAX_T_WAVE) return -2;
+  if (T > HGP_MAX_T_COOP) return -2;
   PotrfArgs a{const_cast<double*>(A), T, b, jitter_rel, add_diag, Linv, nullptr, info};
   a.inv_info = 1;
   hipStream_t st = (hipStream_t)stream;
+  if (T > HGP_MAX_T_WAVE) return T <= 192 ? launch_coop_inv_only<12>(a, st) : launch_coop_inv_only<16>(a, st);
   switch (nb_for(T)) {
     case 2: launch_wave_inv<2>(a, st); break;
     case 4: launch_wave_inv<4>(a, st); break;

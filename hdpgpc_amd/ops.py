@@ -70,16 +70,15 @@ def potrf_batched(A, jitter_rel=1e-8, add_diag=0.0, want_inv=False, want_logdet=
     return tuple(out)
 
 
-def chol_inverse(A, jitter_rel=0.0, add_diag=0.0):
-    """Z = chol(0.5 (A + A^T) + shift I)^{-1} for a batch [b,T,T] (T <= 128; A untouched).  Returns (Z, info)."""
+def chol_inverse(A, jitter_rel=0.0, add_diag=0.0, out=None, info=None):
+    """Z = chol(0.5 (A + A^T) + shift I)^{-1} for a batch [b,T,T] (T <= 256; A untouched).  Returns (Z, info); `out` / `info`
+    may be caller-allocated (capture-safe, no allocation)."""
     A = _dev64(A, "A")
     A3 = A if A.dim() == 3 else A.unsqueeze(0)
     b, T, _ = A3.shape
-    if T > 128:
-        _, info, Z = potrf_batched(A3, jitter_rel, add_diag, want_inv=True)
-        return Z, info
-    Z = torch.empty_like(A3)
-    info = torch.zeros(b, dtype=torch.int32, device=A.device)
+    Z = torch.empty_like(A3) if out is None else out
+    if info is None:
+        info = torch.zeros(b, dtype=torch.int32, device=A.device)
     _ffi.check(_ffi.lib.hgp_chol_inverse_batched_f64(_ptr(A3), T, b, float(jitter_rel), float(add_diag), _ptr(Z), _ptr(info),
                                                      _stream()), "chol_inverse")
     return Z, info

@@ -50,7 +50,8 @@ int hgp_gram_rbf_f64(const double* x, int nx, const double* y, int ny, double c,
 int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add_diag, double* Linv,
                           double* logdet, int32_t* info, void* stream);
 
-/* The inverse of the a3 factor only (A is not modified): Linv[b,T,T] = chol(0.5 (A + A^T) + shift I)^{-1}, T <= 128.
+/* The inverse of the a3 factor only (A is not modified): Linv[b,T,T] = chol(0.5 (A + A^T) + shift I)^{-1}, T <= 256
+ * (one wavefront per block column for T <= 128, one workgroup per block column above).
  * Replaces torch.linalg.solve / inv / cholesky_solve on symmetric positive-definite matrices in the state recursion
  * (GPI.py:144-145,267,295; GPI_model.py:1316,1330): S^{-1} = Linv^T Linv. */
 int hgp_chol_inverse_batched_f64(const double* A, int T, int b, double jitter_rel, double add_diag, double* Linv,

@@ -90,3 +90,27 @@ def test_chol_inverse_with_riding_right_hand_sides(T, rhs_trans):
     got = info2.tolist()
     assert got[0] == 0 and got[2] == 0 and got[1] == 1            # LAPACK-style: first non-positive pivot, 1-based
     assert np.allclose(Y2[0].cpu().numpy(), Y[0].cpu().numpy(), rtol=1e-13, atol=0.0)
+
+
+@pytest.mark.parametrize("T", [90, 144, 192, 256])
+def test_chol_inverse_only_up_to_256_with_caller_buffers(T):
+    """hgp_chol_inverse_batched_f64: Z = L^-1 without touching A, caller-allocated outputs (the graphed member step), LAPACK-style
+    info also from the cooperative kernels (128 < T <= 256)."""
+    from hdpgpc_amd import ops
+    rng = np.random.default_rng(T + 1)
+    b = 3
+    Q = rng.normal(size=(b, T, T))
+    A = Q @ Q.transpose(0, 2, 1) / T + np.eye(T)
+    A[2] = -A[2]                                            # not positive definite: pivot 1 fails
+    dA = dev(A)
+    keep = dA.clone()
+    Z = torch.full((b, T, T), np.nan, dtype=torch.float64, device="cuda")
+    info = torch.full((b,), -3, dtype=torch.int32, device="cuda")
+    Zr, ir = ops.chol_inverse(dA, 0.0, 1e-8, out=Z, info=info)
+    torch.cuda.synchronize()
+    assert Zr.data_ptr() == Z.data_ptr() and ir.data_ptr() == info.data_ptr()
+    assert torch.equal(dA, keep)                            # input untouched
+    assert info.tolist() == [0, 0, 1]
+    for m in range(2):
+        ref = np.linalg.inv(np.linalg.cholesky(0.5 * (A[m] + A[m].T) + 1e-8 * np.eye(T)))
+        assert np.allclose(Z[m].cpu().numpy(), ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
