@@ -18,8 +18,7 @@ def test_rho_omega_and_theta_match_the_reference(fixture):
     start[lab[0]] = 1.0
     trans = np.zeros((M, M))
     np.add.at(trans, (lab[:-1], lab[1:]), 1.0)
-    from hdpgpc_amd.GPI_HDP import _HDP_HYP
-    gamma, trans_alpha, start_alpha, kappa = _HDP_HYP["balanced"]       # the constructor default (GPI_HDP.py:274-291)
+    gamma, trans_alpha, start_alpha, kappa = 1.0, 1.0, 0.1, 0.0          # hdp_hyp = 'balanced', the constructor default (GPI_HDP.py:274-291)
     rho = hdp_global.create_initrho(M)                                   # reinit_global_params, then two rounds (GPI_HDP.py:4006-4011)
     omega = (1.0 + gamma) * np.ones(M)
     for _ in range(2):
