@@ -1649,7 +1649,10 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
     case 2: launch_wave_inv<2>(fa, st); break;
     case 4: launch_wave_inv<4>(fa, st); break;
     case 6: launch_wave_inv<6>(fa, st); break;
-    case 8: launch_wave_inv<8>(fa, st); break;
+    case 8:   // one workgroup per block column (the trailing updates split over its four waves) halves the latency at T = 128
+      if (env_on("HGP_PLAN_WAVE_INV")) launch_wave_inv<8>(fa, st);
+      else launch_coop_inv_only<8>(fa, st);
+      break;
     case 12: launch_coop_potrf<12>(fa, st); break;
     default: launch_coop_potrf<16>(fa, st); break;
   }
