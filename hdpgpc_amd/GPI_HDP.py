@@ -26,6 +26,7 @@ from scipy.special import digamma as _digamma
 from . import hdp_global, ops
 from .GPI import RBFWhiteKernel
 from .GPI_model import GPI_model
+from .offline_loop import OfflineLoop
 
 f64 = torch.float64
 _HDP_HYP = {"less": (0.01, 0.01, 0.01, 0.0), "balanced": (1.0, 1.0, 0.1, 0.0), "more": (10.0, 10.0, 1.0, 0.0)}
@@ -36,7 +37,9 @@ def _first(v):
     return v[0] if isinstance(v, (list, np.ndarray)) and np.ndim(v) > 0 else v
 
 
-class GPI_HDP:
+class GPI_HDP(OfflineLoop):
+    _default_device = "cuda"     # every tensor of this build lives on the GPU
+
     def __init__(self, x_basis, M=None, n_outputs=1, x_basis_warp=None, kernels=None, model_type='dynamic',
                  ini_lengthscale=None, bound_lengthscale=None, ini_gamma=None, ini_sigma=None, ini_outputscale=None,
                  bound_sigma=(1e-10, 1e+10), bound_gamma=(1e-1, 1e+2), bound_noise_warp=(1e-10, 1e+10),
@@ -52,8 +55,8 @@ class GPI_HDP:
         self.M = 1 if M is None else int(M)
         self.n_outputs = int(n_outputs)
         self.verbose = verbose
-        self.cuda = True                       # every tensor of this build lives on the GPU; the flag is kept for the drivers
-        self.device = "cuda"
+        self.cuda = True                       # the flag is kept for the drivers
+        self.device = self._default_device
         self.x_basis_ini = np.asarray(x_basis[0] if isinstance(x_basis, list) else x_basis, dtype=np.float64).reshape(-1, 1)
         self.x_basis = [self.x_basis_ini] * self.M
         self.x_basis_warp = x_basis_warp
@@ -71,6 +74,8 @@ class GPI_HDP:
         self.hmm_switch, self.max_models, self.batch = hmm_switch, max_models, batch
         self.use_snr, self.bayesian_params, self.free_deg_MNIV = use_snr, bayesian_params, free_deg_MNIV
         self.n_explore_steps, self.reestimate_initial_params = n_explore_steps, reestimate_initial_params
+        self.share_gp, self.reduce_outputs, self.reduce_outputs_ratio = share_gp, reduce_outputs, reduce_outputs_ratio
+        self.f_ind_old = torch.zeros(self.M, dtype=torch.int64)
         self.noise_warp, self.mode_warp, self.method_compute_warp = noise_warp, mode_warp, method_compute_warp
         self.static_factor = self.dynamic_factor = 1.0                                        # GPI_HDP.py:181-182
         self.gamma, self.transAlpha, self.startAlpha, self.kappa = _HDP_HYP[hdp_hyp]           # GPI_HDP.py:274-291
@@ -95,6 +100,20 @@ class GPI_HDP:
         gp.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
         gp.fixed_theta = self.fixed_theta
         return gp
+
+    def gpmodel_deepcopy(self, gpmodel):
+        """GPI_HDP.py:4037-4064: a new model object with the same kernel hyper-parameters, priors and (shared, immutable)
+        state tensors; the lists themselves are copied."""
+        g = GPI_model(gpmodel.gp.kernel.clone_with_theta(gpmodel.gp.kernel.theta), gpmodel.x_basis.clone(), annealing=gpmodel.annealing,
+                      bayesian=gpmodel.bayesian, free_deg_MNIV=gpmodel.free_deg_MNIV, verbose=self.verbose)
+        for name in ("y_train", "x_train", "f_star", "f_star_sm", "cov_f", "cov_f_sm", "A", "Gamma", "C", "Sigma", "indexes"):
+            setattr(g, name, list(getattr(gpmodel, name)))
+        g.N, g.fitted, g.ini_cov_def = gpmodel.N, gpmodel.fitted, gpmodel.ini_cov_def
+        g.A_def, g.Gamma_def, g.C_def, g.Sigma_def = gpmodel.A_def, gpmodel.Gamma_def, gpmodel.C_def, gpmodel.Sigma_def
+        g.internal_params, g.observation_params = gpmodel.internal_params, gpmodel.observation_params
+        g.fixed_theta, g.noise_bounds, g.estimation_limit = gpmodel.fixed_theta, gpmodel.noise_bounds, gpmodel.estimation_limit
+        g.gp.fitted = gpmodel.gp.fitted
+        return g
 
     def selected_gpmodels(self):
         return list(range(sum(1 for g in self.gpmodels[0] if len(g.indexes) > 0)))
@@ -133,22 +152,24 @@ class GPI_HDP:
         return rho, omega
 
     def compute_trans_A(self, M):
-        """log transition matrix from the Dirichlet pseudo-counts (GPI_HDP.py:3527-3535); -inf padded up to M states."""
+        """log transition matrix from the Dirichlet pseudo-counts (GPI_HDP.py:3527-3535): the leading M x M block, each row
+        normalised by digamma of the row sum over M + 1 columns (as many as the table has); a table one state short is
+        padded with -inf."""
         tt = _np(self.transTheta)
-        m0 = min(M, tt.shape[0] - 1)
-        tp = _digamma(tt[:m0, :m0]) - _digamma(np.sum(tt[:m0, :m0 + 1], axis=1))[:, None]
-        if m0 == M:
+        tp = _digamma(tt[:M, :M]) - _digamma(np.sum(tt[:M, :M + 1], axis=1))[:, None]
+        if tp.shape[0] == M:
             return torch.as_tensor(tp, dtype=f64)
         out = np.full((M, M), -np.inf)
-        out[:m0, :m0] = tp
+        out[:M - 1, :M - 1] = tp
         return torch.as_tensor(out, dtype=f64)
 
     def compute_trans_pi(self, M, pi):
+        """GPI_HDP.py:3537-3543."""
         pi = torch.as_tensor(_np(pi), dtype=f64).reshape(-1)
         if pi.shape[0] == M:
             return pi
         out = torch.full((M,), -np.inf, dtype=f64)
-        out[:pi.shape[0]] = pi
+        out[:M - 1] = pi
         return out
 
     # ------------------------------------------------------------------ assignment tail (SURVEY.md 8f-3)
@@ -319,11 +340,7 @@ class GPI_HDP:
         self.last_messages = (fmsg, marg, bmsg)
         return ops.assign(fmsg, bmsg).cpu()           # = torch.where(_safe_exp(LogLik(log(alpha beta))) == 1)[1]
 
-    # ------------------------------------------------------------------ the control loop is out of scope
-    def include_batch(self, x_trains, y_trains, it_limit=None, warp=False, with_warp=None):
-        raise NotImplementedError("GPI_HDP.include_batch (birth / merge proposals of the variational loop) is outside the "
-                                  "GP-emission hot path this build covers; see SURVEY.md section 2")
-
+    # ------------------------------------------------------------------ online step: not built yet
     def include_sample(self, x_train, y, with_warp=True, force_model=None, minibatch=0, classify=False):
         raise NotImplementedError("GPI_HDP.include_sample (online variational step) is outside the GP-emission hot path "
                                   "this build covers; see SURVEY.md section 2")

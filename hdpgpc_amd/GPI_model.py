@@ -251,8 +251,10 @@ class GPI_model:
                 ell = 1.2                     # GPI.py:711 overwrites the fitted length-scale
             else:
                 c, ell, noise = self.fixed_theta
-            k = self.gp.kernel
-            k.constant_value, k.length_scale, k.noise_level = float(c), float(ell), float(min(max(noise, lo), hi))
+            # written through log-parameters, as the reference does (GPI.py:707-714: `kernel.k1.k1.theta = np.log([...])`): the
+            # stored value is exp(log(v)), and it is THAT value whose Gram matrix GPI.py:136 later compares bit for bit with
+            # the prior covariance of a copied model (gpmodel_deepcopy clones the kernel through theta again)
+            self.gp.kernel.theta = np.log(np.array([float(c), float(ell), float(min(max(noise, lo), hi))]))
             self.gp.fitted = True
         eye = self._eye()
         alph = alpha_ini[0][0]
@@ -1037,3 +1039,14 @@ class GPI_model:
                                     None, torch.stack(scales).contiguous(), scale_is_diagonal=self._def_diag)
         ops.raise_on_info(info, "return_LDS_param_likelihood")
         return torch.sum(out) / T * 100.0
+
+    def lds_param_likelihood_value(self):
+        """return_LDS_param_likelihood() as a host float, evaluated once per state of the model: the variational loop asks for
+        it at every evaluation of the bound (GPI_HDP.py:1838-1864), mostly for models that have not changed.  Stored with the
+        stack cache, which every method that changes the per-step lists resets."""
+        ent = self._stk.get("_lds_lik")
+        key = (len(self.A), self.A[-1].data_ptr(), self.Sigma[-1].data_ptr(), self.Gamma[-1].data_ptr())
+        if ent is None or ent[0] != key:
+            ent = self._stk["_lds_lik"] = (key, float(self.return_LDS_param_likelihood()))
+        return ent[1]
+

@@ -115,3 +115,56 @@ def find_optimum_rho_omega(sum_log_pi, start_alpha_log_pi, n_doc, gamma, alpha, 
     if init_rho is not None:
         return find_optimum_rho_omega(sum_log_pi, start_alpha_log_pi, n_doc, gamma, alpha, kappa)
     raise ValueError(str(last))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HDP-HMM terms of the variational bound for a HARD assignment (GPI_HDP.py:2651-2750; bnpy's HDPHMMUtil restated).
+def _c_dir(a):
+    """Cumulant of a (row-wise) Dirichlet, summed over rows."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        return gammaln(np.sum(a)) - np.sum(gammaln(a))
+    return np.sum(gammaln(np.sum(a, axis=1))) - np.sum(gammaln(a))
+
+
+def _l_top(rho, omega, alpha, start_alpha, kappa, gamma):
+    """Top-level stick-breaking terms E[log p(u)] - E[log q(u)] plus the constants of the Dirichlet rows."""
+    K = rho.size
+    eta1, eta0 = rho * omega, (1.0 - rho) * omega
+    dg_omega = digamma(omega)
+    e_log_u, e_log_1mu = digamma(eta1) - dg_omega, digamma(eta0) - dg_omega
+    c_beta = lambda a1, a0: np.sum(gammaln(a1 + a0)) - np.sum(gammaln(a1)) - np.sum(gammaln(a0))   # noqa: E731
+    diff_c_beta = K * c_beta(1.0, gamma) - c_beta(eta1, eta0)
+    t_alpha = K * K * np.log(alpha) + K * np.log(start_alpha)
+    kv = np.arange(K, 0, -1, dtype=np.float64)
+    if kappa > 0:
+        coef_u, coef_1mu = K + 1.0 + eta1, K * kv + 1.9 + gamma - eta0      # (the reference's constants, GPI_HDP.py:2717-2718)
+        t_beta = np.sum(rho2beta(rho, "K")) * (np.log(alpha + kappa) - np.log(kappa))
+        t_kappa = K * (np.log(kappa) - np.log(alpha + kappa))
+    else:
+        coef_u, coef_1mu = (K + 1) + 1.0 - eta1, (K + 1) * kv + gamma - eta0
+        t_beta = t_kappa = 0.0
+    return t_alpha + t_kappa + t_beta + diff_c_beta + coef_u @ e_log_u + coef_1mu @ e_log_1mu
+
+
+def elbo_linear_terms(rho, omega, alpha, start_alpha, kappa, gamma, trans_theta, start_theta, start_count, trans_count):
+    """GPI_HDP.calcELBO_LinearTerms (GPI_HDP.py:2651-2680): L_top - cumulants of q(pi) + the slack terms
+    (counts + prior - pseudo-counts) . E[log pi].  The row normaliser of the transition slack is digamma(sum theta)."""
+    rho, omega = np.asarray(rho, dtype=np.float64), np.asarray(omega, dtype=np.float64)
+    trans_theta, start_theta = np.asarray(trans_theta, dtype=np.float64), np.asarray(start_theta, dtype=np.float64)
+    trans_count = np.array(trans_count, dtype=np.float64)
+    K = trans_count.shape[0]
+    ebeta = rho2beta(rho, "K" if start_theta.shape[0] == rho.size else "K+1")
+    l_start = np.inner(start_count + start_alpha * ebeta - start_theta, digamma(start_theta) - digamma(np.sum(start_theta)))
+    prior = alpha * np.tile(ebeta, (K, 1))
+    prior[:, :K] += kappa * np.eye(K)
+    l_trans = np.sum((trans_count + prior - trans_theta) * (digamma(trans_theta) - digamma(np.sum(trans_theta, axis=1))[:, None]))
+    return _l_top(rho, omega, alpha, start_alpha, kappa, gamma) - _c_dir(trans_theta) - _c_dir(start_theta) + l_start + l_trans
+
+
+def elbo_entropy(resp, resp_pair, eps=1e-30):
+    """GPI_HDP.calcELBO_NonlinearTerms (GPI_HDP.py:2682-2700): H[q(z)] from the state and pair tables."""
+    sigma = resp_pair / (resp_pair.sum(axis=2)[:, :, None] + eps) + eps
+    h_table = -np.sum(resp_pair * np.log(sigma), axis=0)
+    h_start = -np.sum(resp * np.log(resp + eps), axis=0)
+    return float(h_table.sum() + h_start.sum())

@@ -592,6 +592,90 @@ def gen_online_t256():
     print("online_t256: done", out["q_shared"][:3])
 
 
+# ------------------------------------- SURVEY 8b Face 1: the offline variational loop, GPI_HDP.include_batch
+def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5):
+    """Run the reference's include_batch exactly as hdpgpc/tests/test_offline.py:32-79 drives it (kernel fit replaced by the
+    theta injection above) and record a TRACE of what the loop decided and computed: every ELBO evaluation
+    (GPI_HDP.compute_q_elbo), every assignment returned by estimate_q_all, every full_pass_weighted, and per EM
+    iteration (variational_local_terms_batch) the assignments and the q / q_lat matrices.  Data only."""
+    import time
+    data = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:n, :, [lead]]
+    N, T, _ = data.shape
+    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data)
+    xb = np.arange(float(T))[:, None]
+    x_trains = np.array([xb] * N)
+    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic",
+                     ini_lengthscale=3.0, bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std,
+                     ini_outputscale=300.0, noise_warp=std * 0.1, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
+                     bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False, method_compute_warp="greedy",
+                     verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
+                     inducing_points=False, reestimate_initial_params=True, n_explore_steps=n_explore, free_deg_MNIV=5)
+    order = []                       # event kinds in call order: 0 elbo, 1 estimate_q_all, 2 full_pass_weighted, 3 EM iteration
+    elbo, qall, fpw, em = [], [], [], []
+    o_elbo, o_qall, o_vltb = sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch
+    o_fpw = GM.GPI_model.full_pass_weighted
+    lab = lambda r: npy(torch.argmax(r, dim=1)).astype(np.int16)   # noqa: E731
+
+    def w_elbo(resp, respPair, q, q_lat, gpmodels, M, *a, **k):
+        out_ = o_elbo(resp, respPair, q, q_lat, gpmodels, M, *a, **k)
+        order.append(0)
+        elbo.append((npy(torch.sum(resp, dim=0)), float(out_[0]), float(out_[1]), float(bool(k.get("post", False)))))
+        return out_
+
+    def w_qall(M, **k):
+        out_ = o_qall(M, **k)
+        order.append(1)
+        qall.append(lab(out_[0]))
+        return out_
+
+    def w_fpw(self, x_trains_, y_trains_, resp, q=None, q_lat=None, snr=None):
+        out_ = o_fpw(self, x_trains_, y_trains_, resp, q=q, q_lat=q_lat, snr=snr)
+        order.append(2)
+        mem = npy(torch.nonzero(resp > 0.99).reshape(-1))
+        fpw.append((float(len(mem)), float(mem[0]) if len(mem) else -1.0, float(mem[-1]) if len(mem) else -1.0,
+                    float(torch.sum(out_[0])) if out_[0] is not None else 0.0,
+                    float(torch.sum(out_[1])) if out_[1] is not None else 0.0))
+        return out_
+
+    def w_vltb(*a, **k):
+        out_ = o_vltb(*a, **k)
+        order.append(3)
+        em.append((lab(out_[0]), npy(out_[2]).copy(), npy(out_[3]).copy(), bool(out_[6])))
+        return out_
+
+    sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch = w_elbo, w_qall, w_vltb
+    GM.GPI_model.full_pass_weighted = w_fpw
+    t0 = time.time()
+    try:
+        sw.include_batch(x_trains, data, warp=False)
+    finally:
+        GM.GPI_model.full_pass_weighted = o_fpw
+    wall = time.time() - t0
+    Mmax = max(len(e[0]) for e in elbo)
+    counts = np.full((len(elbo), Mmax), -1.0)
+    for i, e in enumerate(elbo):
+        counts[i, :len(e[0])] = e[0]
+    out = {"y": data[..., 0], "x_basis": xb[:, 0], "estimators": np.array([std, std_dif, *bound_sigma, *bound_gamma]),
+           "theta_inject": np.array(THETA_INJECT), "n_explore": np.array(n_explore), "wall_s": np.array(wall),
+           "order": np.array(order, dtype=np.int8), "elbo_counts": counts,
+           "elbo_vals": np.array([e[1:] for e in elbo]), "qall_labels": np.stack(qall) if qall else np.zeros((0, N), np.int16),
+           "fpw": np.array(fpw), "n_em": np.array(len(em)), "M_final": np.array(sw.M),
+           "train_elbo": np.array([float(e) for e in sw.train_elbo]),
+           "resp_assigned": np.stack([npy(r).astype(np.int16) for r in sw.resp_assigned]),
+           "f_ind_old": npy(sw.f_ind_old).astype(np.int64), "transTheta": npy(sw.transTheta), "startTheta": npy(sw.startTheta),
+           "rho": npy(sw.rho), "omega": npy(sw.omega), "sigma_def": np.array(float(sw.ini_sigma_def)),
+           "gamma_def": np.array(float(sw.ini_gamma_def)),
+           "counts_final": np.array([len(g.indexes) for g in sw.gpmodels[0]], dtype=np.int64)}
+    for i, (l_, q_, ql_, re_) in enumerate(em):
+        out[f"em{i}_labels"], out[f"em{i}_q"], out[f"em{i}_q_lat"], out[f"em{i}_reallocate"] = l_, q_, ql_, np.array(re_)
+    if n is None or n > 500:          # the full record's beats are already a fixture (mitbih100_lead0.npz)
+        del out["y"]
+    np.savez_compressed(os.path.join(OUT, f"include_batch_{tag}.npz"), **out)
+    print(f"include_batch_{tag}: N={N} wall={wall:.1f}s EM iterations={len(em)} M={sw.M} counts={out['counts_final']} "
+          f"events={len(order)} elbo={out['train_elbo']}")
+
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gram", "score", "pred", "ill", "state", "lml", "warp", "offline"]
     if "gram" in which:
@@ -620,6 +704,10 @@ if __name__ == "__main__":
         gen_warp_batch()
     if "extra" in which:
         gen_producer_extra()
+    if "ib80" in which:
+        gen_include_batch("r100_n80", "100", 80)
+    if "ib100" in which:
+        gen_include_batch("r100", "100", None)
     if "reload" in which:
         gen_reload("r102", "102")
     if "reload2" in which:

@@ -1,0 +1,109 @@
+"""Shared by the CPU and GPU tests of GPI_HDP.include_batch: run the mirror the way hdpgpc/tests/test_offline.py:32-79 drives
+the reference, record the same trace tests/golden/make_golden.py::gen_include_batch records there, and compare the two."""
+import numpy as np
+import torch
+
+
+def run_traced(g, y, it_limit=None):
+    import hdpgpc.GPI_HDP as hdpgp
+    from hdpgpc_amd.GPI_model import GPI_model
+
+    std, std_dif, bs0, bs1, bg0, bg1 = (float(v) for v in g["estimators"])
+    data = np.asarray(y, dtype=np.float64)[:, :, None]
+    N, T, _ = data.shape
+    xb = np.arange(float(T))[:, None]
+    x_trains = np.array([xb] * N)
+    sw = hdpgp.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+                       bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std, ini_outputscale=300.0, noise_warp=std * 0.1,
+                       bound_sigma=(bs0, bs1), bound_gamma=(bg0, bg1), bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False,
+                       method_compute_warp="greedy", verbose=False, hmm_switch=True, max_models=100, mode_warp="rough",
+                       bayesian_params=True, inducing_points=False, reestimate_initial_params=True,
+                       n_explore_steps=int(g["n_explore"]), free_deg_MNIV=5)
+    sw.fixed_theta = tuple(float(v) for v in g["theta_inject"])
+    tr = {"order": [], "elbo": [], "qall": [], "fpw": [], "em": []}
+    o_elbo, o_qall, o_vltb, o_fpw = sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch, GPI_model.full_pass_weighted
+    lab = lambda r: torch.argmax(r, dim=1).numpy().astype(np.int16)   # noqa: E731
+
+    def w_elbo(resp, respPair, q, q_lat, gpmodels, M, *a, **k):
+        out = o_elbo(resp, respPair, q, q_lat, gpmodels, M, *a, **k)
+        tr["order"].append(0)
+        tr["elbo"].append((torch.sum(resp, dim=0).numpy(), float(out[0]), float(out[1]), float(bool(k.get("post", False)))))
+        return out
+
+    def w_qall(M, *a, **k):
+        out = o_qall(M, *a, **k)
+        tr["order"].append(1)
+        tr["qall"].append(lab(out[0]))
+        return out
+
+    def w_fpw(self, x_, y_, resp, q=None, q_lat=None, snr=None, **k):
+        out = o_fpw(self, x_, y_, resp, q=q, q_lat=q_lat, snr=snr, **k)
+        tr["order"].append(2)
+        mem = torch.nonzero(torch.as_tensor(resp) > 0.99).reshape(-1).numpy()
+        tr["fpw"].append((float(len(mem)), float(mem[0]) if len(mem) else -1.0, float(mem[-1]) if len(mem) else -1.0,
+                          float(torch.sum(out[0])) if out[0] is not None else 0.0,
+                          float(torch.sum(out[1])) if out[1] is not None else 0.0))
+        return out
+
+    def w_vltb(*a, **k):
+        out = o_vltb(*a, **k)
+        tr["order"].append(3)
+        tr["em"].append((lab(out[0]), out[2].cpu().numpy().copy(), out[3].cpu().numpy().copy(), bool(out[5])))
+        return out
+
+    sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch = w_elbo, w_qall, w_vltb
+    GPI_model.full_pass_weighted = w_fpw
+    try:
+        sw.include_batch(x_trains, data, with_warp=False, it_limit=it_limit)      # the keyword the reference's drivers use
+    finally:
+        GPI_model.full_pass_weighted = o_fpw
+    return sw, tr
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300)) if a.size else 0.0
+
+
+def compare_trace(g, sw, tr, q_tol=1e-8, n_em=None):
+    """Every decision of the loop (the order of its calls, every assignment it produced) must be IDENTICAL to the reference's;
+    every number it computed (scores, bound terms) within q_tol of the reference's."""
+    from conftest import _note
+
+    n_ref = len(g["order"]) if n_em is None else int(np.nonzero(np.cumsum(g["order"] == 3) == n_em)[0][0]) + 1
+    order = np.array(tr["order"], dtype=np.int8)
+    k = min(len(order), n_ref)
+    first_bad = np.nonzero(order[:k] != g["order"][:k])[0]
+    assert first_bad.size == 0 and len(order) == n_ref, \
+        f"call sequence differs at event {first_bad[:1]} (ours {len(order)} events, reference {n_ref})"
+    n_elbo, n_qall, n_fpw, n_emr = (int(np.sum(order == i)) for i in range(4))
+    # assignments: exact
+    for i in range(n_qall):
+        assert np.array_equal(tr["qall"][i], g["qall_labels"][i]), f"estimate_q_all call {i}: assignments differ"
+    for i in range(n_emr):
+        assert np.array_equal(tr["em"][i][0], g[f"em{i}_labels"]), f"EM iteration {i}: assignments differ"
+        assert tr["em"][i][3] == bool(g[f"em{i}_reallocate"])
+    worst = 0.0
+    for i in range(n_elbo):
+        c = g["elbo_counts"][i]
+        c = c[c >= 0]
+        assert np.array_equal(tr["elbo"][i][0], c), f"bound evaluation {i}: cluster sizes {tr['elbo'][i][0]} vs {c}"
+        assert tr["elbo"][i][3] == g["elbo_vals"][i][2]
+        worst = max(worst, _rel(tr["elbo"][i][1:3], g["elbo_vals"][i][:2]))
+    fp = np.array(tr["fpw"])
+    assert np.array_equal(fp[:, :3], g["fpw"][:n_fpw, :3]), "full_pass_weighted: member sets differ"
+    worst = max(worst, _rel(fp[:, 3:], g["fpw"][:n_fpw, 3:]))
+    for i in range(n_emr):
+        worst = max(worst, _rel(tr["em"][i][1], g[f"em{i}_q"]), _rel(tr["em"][i][2], g[f"em{i}_q_lat"]))
+    _note(worst)
+    assert worst <= q_tol, f"worst relative error {worst:.3e} > {q_tol:.1e}"
+    if n_em is None:
+        assert sw.M == int(g["M_final"])
+        assert np.array_equal(np.array([len(m.indexes) for m in sw.gpmodels[0]]), g["counts_final"])
+        ra = np.stack([r.numpy().astype(np.int16) for r in sw.resp_assigned])
+        assert np.array_equal(ra, g["resp_assigned"])
+        assert _rel(np.array(sw.train_elbo), g["train_elbo"]) <= q_tol
+        assert np.array_equal(sw.f_ind_old.numpy(), g["f_ind_old"])
+        for name in ("transTheta", "startTheta", "rho", "omega"):
+            assert _rel(np.asarray(getattr(sw, name)), g[name]) <= 1e-6, name
+    return worst

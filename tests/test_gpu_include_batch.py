@@ -1,0 +1,44 @@
+"""SURVEY.md 8b Face 1 / BASELINE configs[0]: GPI_HDP.include_batch - the offline variational loop - on the HIP kernels,
+driven as hdpgpc/tests/test_offline.py:32-79 drives the reference and compared with the trace of the reference's own run
+(tests/golden/include_batch_*.npz, written by tests/golden/make_golden.py ib80 / ib100): the loop must take the SAME decisions
+(identical sequence of proposals, identical assignments after every estimate_q_all and every EM iteration) and compute the same
+numbers (every bound evaluation, every full_pass_weighted, q and q_lat of every EM iteration)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from offline_trace import compare_trace, run_traced
+
+pytestmark = pytest.mark.gpu
+
+
+def test_include_batch_r100_first80():
+    g = golden("include_batch_r100_n80.npz")
+    sw, tr = run_traced(g, g["y"])
+    worst = compare_trace(g, sw, tr, q_tol=1e-8)
+    print(f"include_batch, 80 beats: {len(tr['order'])} traced calls, worst relative error {worst:.2e}")
+
+
+def test_include_batch_r100_full():
+    """BASELINE configs[0]: the whole record (2 272 beats) - final counts [2271, 1] as the reference."""
+    g = golden("include_batch_r100.npz")
+    y = golden("mitbih100_lead0.npz")["y"]
+    torch.cuda.synchronize()
+    t0 = time.time()
+    sw, tr = run_traced(g, y)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    worst = compare_trace(g, sw, tr, q_tol=1e-7)
+    print(f"include_batch, record 100: {wall:.1f} s (reference on 8 vCPU: {float(g['wall_s']):.0f} s), worst relative error {worst:.2e}")
+
+
+def test_print_results_after_include_batch(capsys):
+    from hdpgpc.util_plots import print_results
+    g = golden("include_batch_r100_n80.npz")
+    labels = golden("mitbih100_lead0.npz")["labels"]
+    sw, _ = run_traced(g, g["y"])
+    main_model = print_results(sw, labels, 0, error=False)
+    assert len(main_model) == int(g["M_final"]) and sw.selected_gpmodels() == list(range(int(g["M_final"])))
