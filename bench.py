@@ -12,8 +12,11 @@ segment grids (the general path of pred_dist).  At N > 1 GPUs the workload is co
 4 096 rows per GPU at 8 GPUs), cluster state broadcast once from rank 0, scores returned by one all-gather
 (hdpgpc_amd.batch.emission_scores - the function the tests exercise is the function timed here).
 
-Prints ONE JSON line (rank 0).  Run: python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with
+Prints ONE JSON line (rank 0).  Run: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either launch it under
 python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+or just run `python bench.py --gpus N`: without WORLD_SIZE in the environment the process starts that launcher itself as a
+CHILD process (before it has made any GPU call - nothing that touched the GPU is ever re-executed), relays rank 0's line
+and exits with the launcher's code.
 """
 import argparse
 import json
@@ -65,6 +68,47 @@ def cpu_baseline(budget_s=20.0):
             "sample": f"{done} evals of the same workload (T={T_LEN}, {K_CL} clusters): {cpu_s:.1f} CPU-seconds of scoring on "
                       f"{cores} worker processes, one BLAS thread each (slowest worker {slow:.2f} s, {t_wall:.1f} s wall with "
                       f"start-up); NumPy/SciPy oracle"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: run torch.distributed.run as a child process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def secondary_offline_r100(dev):
+    """BASELINE configs[0] / north_star's wall-clock target: GPI_HDP.include_batch on MIT-BIH record 100, lead 0 (2 272 beats,
+    T = 90), driven as hdpgpc/tests/test_offline.py drives the reference, kernel hyper-parameters injected as in the golden run
+    (the gpytorch fit is not part of either number).  The beats are the committed fixture tests/golden/mitbih100_lead0.npz;
+    the reference's own wall-clock for the same call is stored in tests/golden/include_batch_r100.npz (make_golden.py ib100, this
+    build container's 8 vCPUs; SURVEY.md section 6 measured 119.5 s on an idle container)."""
+    gdir = os.path.join(ROOT, "tests", "golden")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from offline_trace import run_model
+    g = np.load(os.path.join(gdir, "include_batch_r100.npz"))
+    y = np.load(os.path.join(gdir, "mitbih100_lead0.npz"))["y"]
+    times = []
+    for _ in range(2):                      # first run includes library / graph warm-up; report both
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sw = run_model(g, y)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    counts = [len(m.indexes) for m in sw.gpmodels[0]]
+    ok = counts == [int(c) for c in g["counts_final"]] and bool(np.array_equal(sw.resp_assigned[-1].numpy(), g["resp_assigned"][-1]))
+    ref = float(g["wall_s"])
+    return {"workload": "BASELINE configs[0]: GPI_HDP.include_batch, MIT-BIH record 100 lead 0 (2272 beats, T=90), settings of "
+                        "hdpgpc/tests/test_offline.py, theta injected",
+            "offline_r100_s": times[1], "first_run_s": times[0], "reference_cpu_s": ref, "reference_cpu_s_survey": 119.5,
+            "speedup_vs_reference": ref / times[1], "speedup_vs_survey": 119.5 / times[1], "final_counts": counts,
+            "assignments_identical_to_reference": ok, "higher_is_better": False}
 
 
 def secondary_shared_grid(dev, ops, S=16384, T=90, reps=10):
@@ -206,9 +250,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))       # no GPU call has been made by this process
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # the CPU baseline (rank 0, N = 1 only) runs before this process touches the GPU
     cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
 
@@ -316,6 +361,7 @@ def main():
             res["strong_scaling_base"] = base
             res["secondary_rank1"] = secondary_rank1(dev, ops)
             res["secondary_matrix_terms"] = secondary_matrix_terms(dev, ops)
+            res["offline_r100"] = secondary_offline_r100(dev)
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)

@@ -4,9 +4,8 @@ import numpy as np
 import torch
 
 
-def run_traced(g, y, it_limit=None):
+def build_model(g, y):
     import hdpgpc.GPI_HDP as hdpgp
-    from hdpgpc_amd.GPI_model import GPI_model
 
     std, std_dif, bs0, bs1, bg0, bg1 = (float(v) for v in g["estimators"])
     data = np.asarray(y, dtype=np.float64)[:, :, None]
@@ -20,6 +19,20 @@ def run_traced(g, y, it_limit=None):
                        bayesian_params=True, inducing_points=False, reestimate_initial_params=True,
                        n_explore_steps=int(g["n_explore"]), free_deg_MNIV=5)
     sw.fixed_theta = tuple(float(v) for v in g["theta_inject"])
+    return sw, x_trains, data
+
+
+def run_model(g, y, it_limit=None):
+    """include_batch with the keyword the reference's drivers use (hdpgpc/tests/test_offline.py:79)."""
+    sw, x_trains, data = build_model(g, y)
+    sw.include_batch(x_trains, data, with_warp=False, it_limit=it_limit)
+    return sw
+
+
+def run_traced(g, y, it_limit=None):
+    from hdpgpc_amd.GPI_model import GPI_model
+
+    sw, x_trains, data = build_model(g, y)
     tr = {"order": [], "elbo": [], "qall": [], "fpw": [], "em": []}
     o_elbo, o_qall, o_vltb, o_fpw = sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch, GPI_model.full_pass_weighted
     lab = lambda r: torch.argmax(r, dim=1).numpy().astype(np.int16)   # noqa: E731
