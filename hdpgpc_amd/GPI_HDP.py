@@ -27,6 +27,7 @@ from . import hdp_global, ops
 from .GPI import RBFWhiteKernel
 from .GPI_model import GPI_model
 from .offline_loop import OfflineLoop
+from .online_loop import OnlineLoop
 
 f64 = torch.float64
 _HDP_HYP = {"less": (0.01, 0.01, 0.01, 0.0), "balanced": (1.0, 1.0, 0.1, 0.0), "more": (10.0, 10.0, 1.0, 0.0)}
@@ -37,7 +38,7 @@ def _first(v):
     return v[0] if isinstance(v, (list, np.ndarray)) and np.ndim(v) > 0 else v
 
 
-class GPI_HDP(OfflineLoop):
+class GPI_HDP(OfflineLoop, OnlineLoop):
     _default_device = "cuda"     # every tensor of this build lives on the GPU
 
     def __init__(self, x_basis, M=None, n_outputs=1, x_basis_warp=None, kernels=None, model_type='dynamic',
@@ -82,7 +83,8 @@ class GPI_HDP(OfflineLoop):
         self.fixed_theta = None
         self.train_elbo, self.resp_assigned, self.q = [], [], []
         self.T = 0
-        self.x_train, self.y_train = [], torch.tensor([])
+        self.x_train, self.y_train, self.y = [], torch.tensor([]), []
+        self.actual_state = 0
         self.fmsg = self.margPrObs = None
         self.elbo_last = None
         self.snr_norm = None
@@ -98,7 +100,7 @@ class GPI_HDP(OfflineLoop):
         gp.noise_bounds = self.bound_sigma_def
         cond = gp.GPR_dynamic(self.ini_gamma_def, self.ini_sigma_def)
         gp.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
-        gp.fixed_theta = self.fixed_theta
+        gp.theta_source = self
         return gp
 
     def gpmodel_deepcopy(self, gpmodel):
@@ -112,6 +114,7 @@ class GPI_HDP(OfflineLoop):
         g.A_def, g.Gamma_def, g.C_def, g.Sigma_def = gpmodel.A_def, gpmodel.Gamma_def, gpmodel.C_def, gpmodel.Sigma_def
         g.internal_params, g.observation_params = gpmodel.internal_params, gpmodel.observation_params
         g.fixed_theta, g.noise_bounds, g.estimation_limit = gpmodel.fixed_theta, gpmodel.noise_bounds, gpmodel.estimation_limit
+        g.theta_source = gpmodel.theta_source
         g.gp.fitted = gpmodel.gp.fitted
         return g
 
@@ -325,10 +328,12 @@ class GPI_HDP(OfflineLoop):
 
     def cluster_new_batch(self, x_trains, y_trains, learning=False, it_limit=None, warp=False):
         """GPI_HDP.py:2975-3003 (learning=False): classify a batch with the frozen models; returns the label tensor."""
-        if learning:
-            raise NotImplementedError("cluster_new_batch(learning=True) re-enters the variational loop: not part of this build")
         x = self.cond_to_torch(x_trains)
         y = self.cond_to_torch(y_trains)
+        if learning:
+            if warp:
+                raise NotImplementedError("warping is not part of this build")
+            return self.cluster_new_batch_learning(x, y, it_limit=it_limit)
         M = self.M
         q = self.frozen_scores(x, y)
         snr = torch.stack([torch.stack([self.compute_snr(y[:, :, ld], self.gpmodels[ld][m]) for ld in range(self.n_outputs)], dim=-1)
@@ -339,11 +344,6 @@ class GPI_HDP(OfflineLoop):
         fmsg, marg, bmsg, _ = self._messages(startPi, q_norm, False)
         self.last_messages = (fmsg, marg, bmsg)
         return ops.assign(fmsg, bmsg).cpu()           # = torch.where(_safe_exp(LogLik(log(alpha beta))) == 1)[1]
-
-    # ------------------------------------------------------------------ online step: not built yet
-    def include_sample(self, x_train, y, with_warp=True, force_model=None, minibatch=0, classify=False):
-        raise NotImplementedError("GPI_HDP.include_sample (online variational step) is outside the GP-emission hot path "
-                                  "this build covers; see SURVEY.md section 2")
 
 
 def _np(a):

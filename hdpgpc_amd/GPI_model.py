@@ -103,6 +103,7 @@ class GPI_model:
         self.internal_params = self.observation_params = None
         self.fitted = False
         self.fixed_theta = None        # (c, ell, noise) taken by fit_kernel_params instead of the gpytorch fit
+        self.theta_source = None       # ... or an owner (GPI_HDP) whose `fixed_theta` is looked up at fit time
         self.noise_bounds = (1e-10, 1e10)
         self._stk = {}
         self._pending = []
@@ -244,13 +245,14 @@ class GPI_model:
         is reset to the INITIAL sigma (GPI_model.py:215-219)."""
         if valid:
             lo, hi = self.noise_bounds
-            if self.fixed_theta is None:      # SURVEY.md 8f-2: Adam on the exact MLL of this first member (kernel_fit.py)
+            fixed = self.fixed_theta if self.fixed_theta is not None else getattr(self.theta_source, "fixed_theta", None)
+            if fixed is None:                 # SURVEY.md 8f-2: Adam on the exact MLL of this first member (kernel_fit.py)
                 from .kernel_fit import fit_kernel_adam
                 c, _, noise, _ = fit_kernel_adam(self.x_basis.reshape(-1).cpu().numpy(), self.cond_to_torch(y).reshape(-1).cpu().numpy(),
                                                  (lo, hi), device=self.device)
                 ell = 1.2                     # GPI.py:711 overwrites the fitted length-scale
             else:
-                c, ell, noise = self.fixed_theta
+                c, ell, noise = fixed
             # written through log-parameters, as the reference does (GPI.py:707-714: `kernel.k1.k1.theta = np.log([...])`): the
             # stored value is exp(log(v)), and it is THAT value whose Gram matrix GPI.py:136 later compares bit for bit with
             # the prior covariance of a copied model (gpmodel_deepcopy clones the kernel through theta again)
@@ -1015,7 +1017,11 @@ class GPI_model:
         out = torch.zeros(n, dtype=f64, device=self.device)
         if self.N == 0 or not bool(torch.any(self.Gamma[-1] != 0)):
             return out
-        out[torch.as_tensor(self.indexes, device=self.device)] = self._lat_all(h_ini)
+        ent = self._stk.get("_lat_all")          # members' scores are kept until the model changes (the online loop asks every
+        key = (h_ini, len(self.indexes), len(self.Gamma), self.f_star_sm[-1].data_ptr(), self.cov_f_sm[-1].data_ptr())
+        if ent is None or ent[0] != key:         # cluster for them at every beat, GPI_HDP.py:1972; only one cluster changes)
+            ent = self._stk["_lat_all"] = (key, self._lat_all(h_ini))
+        out[torch.as_tensor(self.indexes, device=self.device)] = ent[1]
         return out
 
     # ------------------------------------------------------------------ a9

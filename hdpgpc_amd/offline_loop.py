@@ -198,9 +198,10 @@ class OfflineLoop:
         """GPI_HDP.py:1796-1836 -> (emission term, everything else).  q, q_lat: [N, M] device (already combined over the
         leads); resp / respPair: host one-hot tables."""
         n_points = 1 if one_sample else self.x_basis_ini.shape[0]
-        lab = torch.argmax(resp, dim=1).to(q.device)
-        q_bas = float(torch.sum(q.gather(1, lab[:, None]))) * self.static_factor
-        elbo_latent = float(torch.sum(q_lat.gather(1, lab[:, None]))) * self.dynamic_factor
+        rows, cols = torch.where(resp == 1.0)            # q[where(resp == 1)]: rows left without a 1 by a slice contribute nothing
+        rows, cols = rows.to(q.device), cols.to(q.device)
+        q_bas = float(torch.sum(q[rows, cols])) * self.static_factor
+        elbo_latent = float(torch.sum(q_lat[rows, cols])) * self.dynamic_factor
         elbo_lin = self.elbo_Linears(resp, respPair, post=post, one_sample=one_sample) * n_points
         if isinstance(snr, str):                                              # 'saved'
             frac = torch.sum(self.snr_norm, dim=0)
@@ -222,7 +223,12 @@ class OfflineLoop:
         1587-1595, 2856-2862), kernels only: returns host one-hot tables resp [N,K], respPair [N,K,K]."""
         q_norm, _ = self.LogLik(q_w.contiguous())
         fmsg, _, bmsg, pair = self._messages(startPi, q_norm, True)
-        N, K = q_norm.shape
+        return self._one_hot_tables(fmsg, bmsg, pair)
+
+    @staticmethod
+    def _one_hot_tables(fmsg, bmsg, pair):
+        """_safe_exp (GPI_HDP.py:338-350) of the state and pair posteriors as host tables of zeros and ones."""
+        N, K = fmsg.shape
         labels = ops.assign(fmsg, bmsg)
         flat = pair.reshape(N, K * K)
         # first arg-max per row (torch.argmax of the reference on the host; an all -inf row - the first one - gives 0)
@@ -666,12 +672,17 @@ class OfflineLoop:
         snr = self.snr_norm
         if self.reestimate_initial_params:
             self.redefine_default(x, y, resp)
-        startStateCount = transStateCount = None
+        self._em_loop(x, y, resp, respPair, q, q_lat, snr, None, None, it_limit, first_batch=True)
+
+    def _em_loop(self, x, y, resp, respPair, q, q_lat, snr, startStateCount, transStateCount, it_limit, first_batch):
+        """The outer EM iterations shared by include_batch (GPI_HDP.py:861-947) and cluster_new_batch(learning=True)
+        (GPI_HDP.py:3073-3151): proposals + re-assignment, HDP pseudo-counts, the bound, stop when the assignments repeat."""
+        iteration = 0
         reallocate = False
         while True:
             resp, respPair, q, q_lat, snr, end = self.refill(resp, respPair, startStateCount, transStateCount, q, q_lat, snr)
             M = self.M
-            if resp.shape[1] == 1:
+            if first_batch and resp.shape[1] == 1:
                 startStateCount, transStateCount = resp[0].numpy().copy(), torch.sum(respPair, dim=0).numpy()
                 self._update_global(M, transStateCount, startStateCount)
             if end:
@@ -698,21 +709,61 @@ class OfflineLoop:
             self._log("ELBO + Nonlinear: " + str(elbo_))
             iteration += 1
             self._log(f"\n-------Start lower Bound Iteration {iteration}-------")
-            if (it_limit is not None and iteration >= it_limit) or self.M == self.max_models:
+            labels = torch.argmax(resp, dim=1)               # = torch.where(resp == 1.0)[1] for one-hot rows
+            if (it_limit is not None and iteration >= it_limit) or (first_batch and self.M == self.max_models):
                 self.train_elbo.append(elbo_)
-                self.resp_assigned.append(torch.where(resp == 1.0)[1])
+                self.resp_assigned.append(labels)
                 break
             self.train_elbo.append(elbo_)
-            self.resp_assigned.append(torch.argmax(resp, dim=1))
-            self.q.append(q)
+            self.resp_assigned.append(labels)
+            if first_batch:
+                self.q.append(q)
+                self.elbo_last = elbo_
             self.q_last, self.q_lat_last, self.snr_last = q, q_lat, snr
             self.startStateCount_last, self.transStateCount_last = startStateCount, transStateCount
             self.resp_last, self.respPair_last = resp, respPair
-            self.elbo_last = elbo_
             ra = self.resp_assigned
             if (int(torch.sum(self._counts(resp) == 0.0)) > 1 or
                     (len(ra) > 1 and ra[-2].shape[0] == ra[-1].shape[0] and bool(torch.all(ra[-2] == ra[-1])))):
+                if not first_batch:
+                    self.y_train = y
                 break
+            if not first_batch:
+                self.y_train = y
+
+    def cluster_new_batch_learning(self, x_new, y_new, it_limit=None):
+        """GPI_HDP.py:3002-3151, ``cluster_new_batch(learning=True)``: classify the new segments with the frozen models, append
+        them to the stored batch, rebuild every cluster from the joint assignment and run the EM iterations on the whole.
+        (Where the reference's loop meets its stop condition it evaluates an undefined name, ``warp_computed``,
+        GPI_HDP.py:3139 - a NameError; with ``warp=False`` the branch it guards is the plain ``break`` taken here.)"""
+        D, dev = self.n_outputs, self.device
+        q_new = self.frozen_scores(x_new, y_new)
+        snr_new = torch.stack([torch.stack([self.compute_snr(y_new[:, :, ld], self.gpmodels[ld][m]) for ld in range(D)], dim=-1)
+                               for m in range(self.M)], dim=1)
+        _, startPi = self._log_pis(self.M, self.transTheta, self.startTheta)
+        resp_new, respPair_new = self._assign(self.weight_mean(q_new, snr_new), startPi)
+        x = torch.cat([self.x_train, x_new])
+        y = torch.cat([self.y_train, y_new])
+        N = self.T = y.shape[0]
+        resp = torch.cat([self.resp_last, resp_new])
+        respPair = torch.cat([self.respPair_last, respPair_new])
+        self.snr_norm = torch.cat([self.snr_norm, self.normalize_snr(snr_new)])
+        reorder = torch.argsort(self._counts(resp), descending=True)
+        resp = resp[:, reorder]                                                # quirk: the pair table keeps the old order
+        q = torch.zeros((N, self.M, D), dtype=f64, device=dev)
+        q_lat, snr = torch.zeros_like(q), torch.zeros_like(q)
+        models = [[] for _ in range(D)]
+        for ld in range(D):
+            for m in range(self.M):
+                gp = self._fresh_copy(self.gpmodels[ld][int(reorder[m])])
+                q[:, m, ld], q_lat[:, m, ld] = self._full_pass(gp, x, y, ld, resp[:, m], None, None)
+                snr[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
+                models[ld].append(gp)
+        self.gpmodels = models
+        resp, respPair = self._assign(self.weight_mean(q, snr), startPi)
+        self.x_train = x
+        self._em_loop(x, y, resp, respPair, q, q_lat, snr, resp[0].numpy().copy(), torch.sum(respPair, dim=0).numpy(), it_limit,
+                      first_batch=False)
 
     def _update_global(self, M, transStateCount, startStateCount):
         """GPI_HDP.py:868-873 / 897-902: pseudo-counts from the hard assignment, two rounds of the (rho, omega) optimiser."""

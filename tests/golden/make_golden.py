@@ -461,6 +461,24 @@ def gen_reload(tag, rec, n=None, leads=(0,)):
     sw.reload_model_from_labels(x_trains, data, lab, M)
     new_labels = sw.cluster_new_batch(x_trains, data)
     first = (lambda a: a[..., 0]) if D == 1 else (lambda a: a)      # the one-lead fixture keeps its round-2 layout
+    ref_sens = None
+    if D > 1:
+        # how sharply are the REFERENCE's numbers defined?  Its own run on inputs perturbed by 1e-15 relative (below one ulp):
+        # the per-(lead, class) change of its scores is the yardstick the parity test uses for the ill-conditioned lead
+        sw2 = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=D, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+                          bound_lengthscale=(1.0, 20.0), ini_gamma=gamma, ini_sigma=sigma, ini_outputscale=300.0,
+                          noise_warp=noise_warp, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
+                          bound_noise_warp=(noise_warp * 0.1, noise_warp * 0.2), warp_updating=False, method_compute_warp="greedy",
+                          verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
+                          inducing_points=False, reestimate_initial_params=True, n_explore_steps=20, free_deg_MNIV=5)
+        data_p = data * (1.0 + 1e-15 * np.random.default_rng(0).standard_normal(data.shape))
+        sw2.reload_model_from_labels(x_trains, data_p, lab, M)
+        qa, qb = npy(sw.q_last), npy(sw2.q_last)
+        la, lb = npy(sw.q_lat_last), npy(sw2.q_lat_last)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ref_sens = np.maximum(np.max(np.abs(qb - qa) / np.abs(qa), axis=0),
+                                  np.nanmax(np.where(la != 0, np.abs(lb - la) / np.abs(la), 0.0), axis=0))    # [M, D]
+        print("reference sensitivity to a 1e-15 input perturbation [class, lead]:\n", ref_sens)
     out = {"y": first(data), "x_basis": xb[:, 0], "labels": lab.astype(np.int64), "M": np.array(M),
            "estimators": np.array([std, std_dif, bound_sigma[0], bound_sigma[1], bound_gamma[0], bound_gamma[1]]),
            "sigma": np.array(sigma), "gamma": np.array(gamma), "theta_inject": np.array(THETA_INJECT),
@@ -478,6 +496,8 @@ def gen_reload(tag, rec, n=None, leads=(0,)):
                 out[f"m{m}_theta"] = kernel_theta(g.gp.kernel)
                 out[f"m{m}_n_members"] = np.array(len(g.indexes))
     out["q_new"] = first(qn)
+    if ref_sens is not None:
+        out["ref_sens"] = ref_sens
     np.savez_compressed(os.path.join(OUT, f"reload_{tag}.npz"), **out)
     print(f"reload_{tag}: N={N} M={M} counts={[len(g.indexes) for g in sw.gpmodels[0]]} "
           f"changed labels={int(np.sum(out['new_labels'] != lab))}")
@@ -592,24 +612,10 @@ def gen_online_t256():
     print("online_t256: done", out["q_shared"][:3])
 
 
-# ------------------------------------- SURVEY 8b Face 1: the offline variational loop, GPI_HDP.include_batch
-def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5):
-    """Run the reference's include_batch exactly as hdpgpc/tests/test_offline.py:32-79 drives it (kernel fit replaced by the
-    theta injection above) and record a TRACE of what the loop decided and computed: every ELBO evaluation
-    (GPI_HDP.compute_q_elbo), every assignment returned by estimate_q_all, every full_pass_weighted, and per EM
-    iteration (variational_local_terms_batch) the assignments and the q / q_lat matrices.  Data only."""
+def _trace_loop(sw, run):
+    """Run `run()` with GPI_HDP.compute_q_elbo / estimate_q_all / variational_local_terms_batch and GPI_model.full_pass_weighted
+    wrapped; returns (order, elbo, qall, fpw, em, wall seconds, exception or None)."""
     import time
-    data = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:n, :, [lead]]
-    N, T, _ = data.shape
-    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data)
-    xb = np.arange(float(T))[:, None]
-    x_trains = np.array([xb] * N)
-    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic",
-                     ini_lengthscale=3.0, bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std,
-                     ini_outputscale=300.0, noise_warp=std * 0.1, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
-                     bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False, method_compute_warp="greedy",
-                     verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
-                     inducing_points=False, reestimate_initial_params=True, n_explore_steps=n_explore, free_deg_MNIV=5)
     order = []                       # event kinds in call order: 0 elbo, 1 estimate_q_all, 2 full_pass_weighted, 3 EM iteration
     elbo, qall, fpw, em = [], [], [], []
     o_elbo, o_qall, o_vltb = sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch
@@ -646,34 +652,154 @@ def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5):
     sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch = w_elbo, w_qall, w_vltb
     GM.GPI_model.full_pass_weighted = w_fpw
     t0 = time.time()
+    err = None
     try:
-        sw.include_batch(x_trains, data, warp=False)
+        run()
+    except NameError as e:           # GPI_HDP.py:3139 reads an undefined name at the loop's stop condition (cluster_new_batch)
+        err = e
     finally:
         GM.GPI_model.full_pass_weighted = o_fpw
-    wall = time.time() - t0
+        sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch = o_elbo, o_qall, o_vltb
+    return order, elbo, qall, fpw, em, time.time() - t0, err
+
+
+def _pack_trace(out, N, order, elbo, qall, fpw, em):
     Mmax = max(len(e[0]) for e in elbo)
     counts = np.full((len(elbo), Mmax), -1.0)
     for i, e in enumerate(elbo):
         counts[i, :len(e[0])] = e[0]
+    out.update({"order": np.array(order, dtype=np.int8), "elbo_counts": counts, "elbo_vals": np.array([e[1:] for e in elbo]),
+                "qall_labels": np.stack(qall) if qall else np.zeros((0, N), np.int16), "fpw": np.array(fpw), "n_em": np.array(len(em))})
+    for i, (l_, q_, ql_, re_) in enumerate(em):
+        out[f"em{i}_labels"], out[f"em{i}_q"], out[f"em{i}_q_lat"], out[f"em{i}_reallocate"] = l_, q_, ql_, np.array(re_)
+
+
+# ------------------------------------- SURVEY 8b Face 1: the offline variational loop, GPI_HDP.include_batch
+def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5):
+    """Run the reference's include_batch exactly as hdpgpc/tests/test_offline.py:32-79 drives it (kernel fit replaced by the
+    theta injection above) and record a TRACE of what the loop decided and computed: every ELBO evaluation
+    (GPI_HDP.compute_q_elbo), every assignment returned by estimate_q_all, every full_pass_weighted, and per EM
+    iteration (variational_local_terms_batch) the assignments and the q / q_lat matrices.  Data only."""
+    data = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:n, :, [lead]]
+    N, T, _ = data.shape
+    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data)
+    xb = np.arange(float(T))[:, None]
+    x_trains = np.array([xb] * N)
+    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic",
+                     ini_lengthscale=3.0, bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std,
+                     ini_outputscale=300.0, noise_warp=std * 0.1, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
+                     bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False, method_compute_warp="greedy",
+                     verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
+                     inducing_points=False, reestimate_initial_params=True, n_explore_steps=n_explore, free_deg_MNIV=5)
+    order, elbo, qall, fpw, em, wall, _ = _trace_loop(sw, lambda: sw.include_batch(x_trains, data, warp=False))
     out = {"y": data[..., 0], "x_basis": xb[:, 0], "estimators": np.array([std, std_dif, *bound_sigma, *bound_gamma]),
            "theta_inject": np.array(THETA_INJECT), "n_explore": np.array(n_explore), "wall_s": np.array(wall),
-           "order": np.array(order, dtype=np.int8), "elbo_counts": counts,
-           "elbo_vals": np.array([e[1:] for e in elbo]), "qall_labels": np.stack(qall) if qall else np.zeros((0, N), np.int16),
-           "fpw": np.array(fpw), "n_em": np.array(len(em)), "M_final": np.array(sw.M),
-           "train_elbo": np.array([float(e) for e in sw.train_elbo]),
+           "M_final": np.array(sw.M), "train_elbo": np.array([float(e) for e in sw.train_elbo]),
            "resp_assigned": np.stack([npy(r).astype(np.int16) for r in sw.resp_assigned]),
            "f_ind_old": npy(sw.f_ind_old).astype(np.int64), "transTheta": npy(sw.transTheta), "startTheta": npy(sw.startTheta),
            "rho": npy(sw.rho), "omega": npy(sw.omega), "sigma_def": np.array(float(sw.ini_sigma_def)),
            "gamma_def": np.array(float(sw.ini_gamma_def)),
            "counts_final": np.array([len(g.indexes) for g in sw.gpmodels[0]], dtype=np.int64)}
-    for i, (l_, q_, ql_, re_) in enumerate(em):
-        out[f"em{i}_labels"], out[f"em{i}_q"], out[f"em{i}_q_lat"], out[f"em{i}_reallocate"] = l_, q_, ql_, np.array(re_)
+    _pack_trace(out, N, order, elbo, qall, fpw, em)
     if n is None or n > 500:          # the full record's beats are already a fixture (mitbih100_lead0.npz)
         del out["y"]
     np.savez_compressed(os.path.join(OUT, f"include_batch_{tag}.npz"), **out)
     print(f"include_batch_{tag}: N={N} wall={wall:.1f}s EM iterations={len(em)} M={sw.M} counts={out['counts_final']} "
           f"events={len(order)} elbo={out['train_elbo']}")
 
+
+
+# ------------------------------------- SURVEY 8b Face 1 / configs[4]: the online step, GPI_HDP.include_sample
+def gen_include_sample(tag, rec, n, T_res=None, lead=0):
+    """Run the reference's online loop as hdpgpc/tests/test_online.py:41-83 drives it (n_f = 30, free_deg_MNIV = 20, warp
+    off, theta injected) on the first n beats of a record - optionally resampled to T_res points by linear interpolation
+    (BASELINE configs[4] names T = 256) - and record after every beat what the step decided and scored."""
+    import time
+    raw = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:, :, [lead]]
+    if T_res is not None:
+        tt = np.linspace(0, raw.shape[1] - 1, T_res)
+        raw = np.stack([np.interp(tt, np.arange(raw.shape[1]), r[:, 0]) for r in raw[:max(n, 32)]])[:, :, None]
+    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(raw, 30)
+    data = np.ascontiguousarray(raw[:n])
+    T = data.shape[1]
+    xb = np.arange(float(T))[:, None]
+    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+                     bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std, ini_outputscale=300.0, noise_warp=std * 0.1,
+                     bound_sigma=bound_sigma, bound_gamma=bound_gamma, bound_noise_warp=(std * 0.01, std * 0.02),
+                     warp_updating=False, method_compute_warp="greedy", verbose=False, hmm_switch=True, max_models=100,
+                     mode_warp="rough", bayesian_params=True, inducing_points=False, estimation_limit=None, free_deg_MNIV=20)
+    out = {"y": data[..., 0], "x_basis": xb[:, 0], "estimators": np.array([std, std_dif, *bound_sigma, *bound_gamma]),
+           "theta_inject": np.array(THETA_INJECT)}
+    states, Ms, secs = [], [], []
+    for i in range(n):
+        t0 = time.time()
+        sw.include_sample(xb, data[i], with_warp=False)
+        secs.append(time.time() - t0)
+        states.append(sw.actual_state)
+        Ms.append(sw.M)
+        out[f"b{i}_labels"] = npy(sw.resp_assigned[-1]).astype(np.int16)
+        out[f"b{i}_q"] = npy(sw.q[-1]).copy()
+        out[f"b{i}_counts"] = np.array([len(g.indexes) for g in sw.gpmodels[0]], dtype=np.int64)
+    out["state"], out["M"], out["secs"] = np.array(states), np.array(Ms), np.array(secs)
+    out["transTheta"], out["startTheta"], out["rho"], out["omega"] = npy(sw.transTheta), npy(sw.startTheta), npy(sw.rho), npy(sw.omega)
+    np.savez_compressed(os.path.join(OUT, f"include_sample_{tag}.npz"), **out)
+    print(f"include_sample_{tag}: n={n} T={T} states={states} M={Ms[-1]} total {sum(secs):.1f}s last beat {secs[-1]:.2f}s")
+
+
+# ------------------------------------- cluster_new_batch(learning=True): the EM loop re-entered with new segments
+def gen_cluster_learning(tag, rec, n0, n1, leads=(0, 1), n_explore=5):
+    """As hdpgpc/tests/test_offline_multi_output_load.py:81-85 (both leads): rebuild the cluster models of the first n0 beats
+    from the annotation labels, then cluster_new_batch(the next n1 beats, learning=True).  The reference's loop ends in a
+    NameError (GPI_HDP.py:3139, `warp_computed`) after its last assignment; the state at that point is what is recorded."""
+    data = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:n0 + n1, :, list(leads)]
+    labels = np.load(os.path.join(REF, "data", "mitbih", f"{rec}_labels.npy"))[:n0]
+    N, T, D = data.shape
+    std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data, n_f=50)
+    xb = np.arange(float(T))[:, None]
+    x_trains = np.array([xb] * N)
+    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=D, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+                     bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std, ini_outputscale=300.0, noise_warp=std * 0.1,
+                     bound_sigma=bound_sigma, bound_gamma=bound_gamma, bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False,
+                     method_compute_warp="greedy", verbose=False, hmm_switch=True, max_models=100, mode_warp="rough",
+                     bayesian_params=True, inducing_points=False, reestimate_initial_params=True, n_explore_steps=n_explore,
+                     free_deg_MNIV=5)
+    sw.warp = False                      # include_batch sets it; cluster_new_batch reads it through the proposals
+    vals = np.unique(labels)
+    lab = np.array([int(np.where(vals == l_)[0][0]) for l_ in labels])
+    sw.reload_model_from_labels(x_trains[:n0], data[:n0], lab, len(vals))
+    order, elbo, qall, fpw, em, wall, err = _trace_loop(
+        sw, lambda: sw.cluster_new_batch(x_trains[n0:], data[n0:], learning=True))
+    out = {"y": data, "x_basis": xb[:, 0], "estimators": np.array([std, std_dif, *bound_sigma, *bound_gamma]), "labels": lab,
+           "n0": np.array(n0), "M0": np.array(len(vals)), "theta_inject": np.array(THETA_INJECT), "n_explore": np.array(n_explore),
+           "wall_s": np.array(wall), "ended_in_nameerror": np.array(err is not None), "M_final": np.array(sw.M),
+           "train_elbo": np.array([float(e) for e in sw.train_elbo]),
+           "resp_last": npy(torch.argmax(sw.resp_assigned[-1].reshape(N, -1), dim=1) if sw.resp_assigned[-1].dim() > 1
+                            else sw.resp_assigned[-1]).astype(np.int16),
+           "counts_final": np.array([[len(g.indexes) for g in sw.gpmodels[ld]] for ld in range(D)], dtype=np.int64),
+           "q_last": npy(sw.q_last), "q_lat_last": npy(sw.q_lat_last)}
+    _pack_trace(out, N, order, elbo, qall, fpw, em)
+    # the reference's own sensitivity: the same run on inputs perturbed by 1e-15 relative (below one ulp)
+    data_p = data * (1.0 + 1e-15 * np.random.default_rng(0).standard_normal(data.shape))
+    sw2 = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=D, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+                      bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std, ini_outputscale=300.0, noise_warp=std * 0.1,
+                      bound_sigma=bound_sigma, bound_gamma=bound_gamma, bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False,
+                      method_compute_warp="greedy", verbose=False, hmm_switch=True, max_models=100, mode_warp="rough",
+                      bayesian_params=True, inducing_points=False, reestimate_initial_params=True, n_explore_steps=n_explore,
+                      free_deg_MNIV=5)
+    sw2.warp = False
+    sw2.reload_model_from_labels(x_trains[:n0], data_p[:n0], lab, len(vals))
+    o2, e2, qa2, f2, em2, _, _ = _trace_loop(sw2, lambda: sw2.cluster_new_batch(x_trains[n0:], data_p[n0:], learning=True))
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(np.asarray(b)))), 1e-300))  # noqa: E731
+    same = o2 == order and all(np.array_equal(a, b) for a, b in zip(qa2, qall))
+    out["ref_pert_same_decisions"] = np.array(same)
+    if same:
+        sens = max([rel(a[1:3], b[1:3]) for a, b in zip(e2, elbo)] + [rel(a[3:], b[3:]) for a, b in zip(f2, fpw)] +
+                   [max(rel(a[1], b[1]), rel(a[2], b[2])) for a, b in zip(em2, em)])
+        out["ref_sens"] = np.array(sens)
+        print("reference sensitivity of the traced numbers to a 1e-15 input perturbation:", sens)
+    np.savez_compressed(os.path.join(OUT, f"cluster_learning_{tag}.npz"), **out)
+    print(f"cluster_learning_{tag}: N={N} D={D} wall={wall:.1f}s EM iterations={len(em)} M={sw.M} counts={out['counts_final'].tolist()} "
+          f"events={len(order)} err={err}")
 
 
 if __name__ == "__main__":
@@ -708,6 +834,12 @@ if __name__ == "__main__":
         gen_include_batch("r100_n80", "100", 80)
     if "ib100" in which:
         gen_include_batch("r100", "100", None)
+    if "learn" in which:
+        gen_cluster_learning("r102_2leads", "102", 300, 20)
+    if "online90" in which:
+        gen_include_sample("r102_n40", "102", 40)
+    if "online256" in which and "trace" in which:
+        gen_include_sample("r102_t256_n24", "102", 24, T_res=256)
     if "reload" in which:
         gen_reload("r102", "102")
     if "reload2" in which:

@@ -29,10 +29,10 @@ def run_model(g, y, it_limit=None):
     return sw
 
 
-def run_traced(g, y, it_limit=None):
+def traced(sw, run):
+    """run() with the loop's entry points wrapped like tests/golden/make_golden.py::_trace_loop wraps the reference's."""
     from hdpgpc_amd.GPI_model import GPI_model
 
-    sw, x_trains, data = build_model(g, y)
     tr = {"order": [], "elbo": [], "qall": [], "fpw": [], "em": []}
     o_elbo, o_qall, o_vltb, o_fpw = sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch, GPI_model.full_pass_weighted
     lab = lambda r: torch.argmax(r, dim=1).numpy().astype(np.int16)   # noqa: E731
@@ -67,9 +67,38 @@ def run_traced(g, y, it_limit=None):
     sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch = w_elbo, w_qall, w_vltb
     GPI_model.full_pass_weighted = w_fpw
     try:
-        sw.include_batch(x_trains, data, with_warp=False, it_limit=it_limit)      # the keyword the reference's drivers use
+        run()
     finally:
         GPI_model.full_pass_weighted = o_fpw
+        sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch = o_elbo, o_qall, o_vltb
+    return tr
+
+
+def run_traced(g, y, it_limit=None):
+    sw, x_trains, data = build_model(g, y)
+    return sw, traced(sw, lambda: sw.include_batch(x_trains, data, with_warp=False, it_limit=it_limit))   # the drivers' keyword
+
+
+def run_cluster_learning(g):
+    """hdpgpc/tests/test_offline_multi_output_load.py:81-85 on the fixture's beats: reload_model_from_labels on the first n0,
+    cluster_new_batch(the rest, learning=True)."""
+    import hdpgpc.GPI_HDP as hdpgp
+
+    std, std_dif, bs0, bs1, bg0, bg1 = (float(v) for v in g["estimators"])
+    data = np.asarray(g["y"], dtype=np.float64)
+    N, T, D = data.shape
+    n0 = int(g["n0"])
+    xb = np.arange(float(T))[:, None]
+    x_trains = np.array([xb] * N)
+    sw = hdpgp.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=D, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+                       bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std, ini_outputscale=300.0, noise_warp=std * 0.1,
+                       bound_sigma=(bs0, bs1), bound_gamma=(bg0, bg1), bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False,
+                       method_compute_warp="greedy", verbose=False, hmm_switch=True, max_models=100, mode_warp="rough",
+                       bayesian_params=True, inducing_points=False, reestimate_initial_params=True,
+                       n_explore_steps=int(g["n_explore"]), free_deg_MNIV=5)
+    sw.fixed_theta = tuple(float(v) for v in g["theta_inject"])
+    sw.reload_model_from_labels(x_trains[:n0], data[:n0], g["labels"], int(g["M0"]))
+    tr = traced(sw, lambda: sw.cluster_new_batch(x_trains[n0:], data[n0:], learning=True))
     return sw, tr
 
 
@@ -110,7 +139,13 @@ def compare_trace(g, sw, tr, q_tol=1e-8, n_em=None):
         worst = max(worst, _rel(tr["em"][i][1], g[f"em{i}_q"]), _rel(tr["em"][i][2], g[f"em{i}_q_lat"]))
     _note(worst)
     assert worst <= q_tol, f"worst relative error {worst:.3e} > {q_tol:.1e}"
-    if n_em is None:
+    if n_em is None and "q_last" in g:                       # cluster_new_batch(learning=True) fixture
+        assert sw.M == int(g["M_final"])
+        assert np.array_equal(np.array([[len(m.indexes) for m in lead] for lead in sw.gpmodels]), g["counts_final"])
+        assert np.array_equal(sw.resp_assigned[-1].numpy().astype(np.int16), g["resp_last"])
+        assert _rel(np.array(sw.train_elbo), g["train_elbo"]) <= q_tol
+        assert _rel(sw.q_last.cpu().numpy(), g["q_last"]) <= q_tol and _rel(sw.q_lat_last.cpu().numpy(), g["q_lat_last"]) <= q_tol
+    elif n_em is None:
         assert sw.M == int(g["M_final"])
         assert np.array_equal(np.array([len(m.indexes) for m in sw.gpmodels[0]]), g["counts_final"])
         ra = np.stack([r.numpy().astype(np.int16) for r in sw.resp_assigned])

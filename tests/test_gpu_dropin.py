@@ -133,10 +133,11 @@ def test_frozen_scores_mixed_grids_match_per_segment_calls():
     assert sw_gp.cluster_new_batch(xs, data[:12]).shape == (12,)
 
 
-def test_control_loop_is_out_of_scope_and_says_so():
+def test_unbuilt_options_say_so():
+    """What this build does not cover raises instead of silently doing something else: warping inside the loops."""
     g = golden("reload_r102.npz")
     sw_gp, x_trains, data = _driver(g)
     with pytest.raises(NotImplementedError):
-        sw_gp.include_batch(x_trains[:4], data[:4], with_warp=False)
+        sw_gp.include_batch(x_trains[:4], data[:4], with_warp=True)
     with pytest.raises(NotImplementedError):
-        sw_gp.include_sample(x_trains[0], data[0], with_warp=False)
+        sw_gp.include_sample(x_trains[0], data[0], with_warp=True)

@@ -33,3 +33,12 @@ def test_hdp_elbo_terms_finite():
     pair = np.zeros((5, 3, 3))
     pair[np.arange(1, 5), [0, 0, 1, 2], [0, 1, 2, 0]] = 1.0
     assert abs(hg.elbo_entropy(resp, pair)) < 1e-20
+
+
+def test_include_sample_trace_cpu(monkeypatch):
+    """Host logic of the online step (GPI_HDP.include_sample) against the reference's own 40-beat run on record 102."""
+    from online_trace import compare_online, run_online
+    cpu_double.install(monkeypatch)
+    g = golden("include_sample_r102_n40.npz")
+    _, tr = run_online(g)
+    compare_online(g, tr, 1e-9)
