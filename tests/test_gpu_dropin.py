@@ -69,10 +69,11 @@ def test_reload_and_classify_both_leads_as_the_driver_is_written():
     (tests/golden/reload_r102_2leads.npz): score tensors per lead, pseudo-counts, and the label tensor exactly.
 
     Tolerance.  Lead 0 is held to 1e-7 like the one-lead fixture.  On lead 1 the recursion itself is ill-conditioned (the
-    injected kernel noise does not fit that lead's amplitude): perturbing the INPUT beats by 1e-15 relative - less than one
-    ulp - moves this implementation's own scores of classes 2 and 3 by up to 6e-7 and 2e-5, so the reference's numbers are
-    not defined more sharply than that either.  The gate is therefore calibrated per (lead, class) on that measured
-    sensitivity: |ours - reference| <= max(1e-7, 50 x the change under the sub-ulp perturbation).  Labels: identical."""
+    injected kernel noise does not fit that lead's amplitude).  The yardstick comes from the REFERENCE, not from this code:
+    make_golden.py reran the reference's own reload_model_from_labels on inputs perturbed by 1e-15 relative - less than one
+    ulp - and stored how far its scores move per (class, lead) (``ref_sens``: 1.4e-6 and 1.9e-4 for classes 2 and 3 of lead
+    1, <= 1.3e-9 everywhere else).  Gate: |ours - reference| <= max(1e-7, 50 x ref_sens[class, lead]), a fixed number.
+    Labels: identical."""
     g = golden("reload_r102_2leads.npz")
     M = int(g["M"])
 
@@ -91,22 +92,20 @@ def test_reload_and_classify_both_leads_as_the_driver_is_written():
     assert np.allclose(sw_gp.transTheta, g["transTheta"], rtol=1e-8) and np.allclose(sw_gp.startTheta, g["startTheta"], rtol=1e-8)
     assert np.allclose(sw_gp.rho, g["rho"], rtol=1e-9) and np.allclose(sw_gp.omega, g["omega"], rtol=1e-9)
     q = sw_gp.q_last.cpu().numpy()
-    q_pert = run(1e-15)[0].q_last.cpu().numpy()
     xt, yt = sw_gp.cond_to_torch(x_trains), sw_gp.cond_to_torch(data)
     q_new = sw_gp.frozen_scores(xt, yt).cpu().numpy()
     members = g["q_lat_last"] != 0.0
     q_lat = sw_gp.q_lat_last.cpu().numpy()
     rel = lambda a, b: np.abs(a - b) / np.abs(b)      # noqa: E731
+    assert float(g["ref_sens"][:, 0].max()) < 2e-9                      # the reference itself: lead 0 is well conditioned
     for ld in range(2):
         for m in range(M):
-            sens = float(rel(q_pert[:, m, ld], q[:, m, ld]).max())
-            gate = max(1e-7, 50.0 * sens)
-            assert ld == 1 or gate == 1e-7, (ld, m, sens)              # lead 0 is well conditioned
-            assert float(rel(q[:, m, ld], g["q_last"][:, m, ld]).max()) <= gate, (ld, m, sens)
-            assert float(rel(q_new[:, m, ld], g["q_new"][:, m, ld]).max()) <= gate, (ld, m, sens)
+            gate = max(1e-7, 50.0 * float(g["ref_sens"][m, ld]))
+            assert float(rel(q[:, m, ld], g["q_last"][:, m, ld]).max()) <= gate, (ld, m, gate)
+            assert float(rel(q_new[:, m, ld], g["q_new"][:, m, ld]).max()) <= gate, (ld, m, gate)
             mem = members[:, m, ld]
             if mem.any():
-                assert float(rel(q_lat[mem, m, ld], g["q_lat_last"][mem, m, ld]).max()) <= gate, (ld, m, sens)
+                assert float(rel(q_lat[mem, m, ld], g["q_lat_last"][mem, m, ld]).max()) <= gate, (ld, m, gate)
     new_labels = sw_gp.cluster_new_batch(x_trains, data)
     assert np.array_equal(new_labels.numpy(), g["new_labels"])           # bit-identical assignments
     assert int(np.sum(g["new_labels"] != g["labels"])) == 7               # (the frozen models disagree with 7 annotations)

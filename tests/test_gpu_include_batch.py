@@ -42,3 +42,17 @@ def test_print_results_after_include_batch(capsys):
     sw, _ = run_traced(g, g["y"])
     main_model = print_results(sw, labels, 0, error=False)
     assert len(main_model) == int(g["M_final"]) and sw.selected_gpmodels() == list(range(int(g["M_final"])))
+
+
+def test_cluster_new_batch_learning_two_leads():
+    """cluster_new_batch(learning=True) as hdpgpc/tests/test_offline_multi_output_load.py:85 calls it, BOTH leads: 300 beats of
+    record 102 rebuilt from their labels, 20 new beats classified and the EM loop re-entered on all 320 (the reference's run
+    ends in a NameError at its stop condition, GPI_HDP.py:3139; its state at that point is the fixture).  Decisions identical;
+    numbers within 50 x the reference's OWN change under a sub-ulp perturbation of the inputs (stored in the fixture: 1.9e-7 -
+    lead 1 is ill-conditioned, see test_gpu_dropin.py)."""
+    from offline_trace import run_cluster_learning
+    g = golden("cluster_learning_r102_2leads.npz")
+    assert bool(g["ref_pert_same_decisions"])
+    sw, tr = run_cluster_learning(g)
+    worst = compare_trace(g, sw, tr, q_tol=max(1e-8, 50.0 * float(g["ref_sens"])))
+    print(f"cluster_new_batch(learning=True), 2 leads: {len(tr['order'])} traced calls, worst relative error {worst:.2e}")

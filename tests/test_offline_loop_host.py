@@ -42,3 +42,13 @@ def test_include_sample_trace_cpu(monkeypatch):
     g = golden("include_sample_r102_n40.npz")
     _, tr = run_online(g)
     compare_online(g, tr, 1e-9)
+
+
+def test_cluster_new_batch_learning_two_leads_cpu(monkeypatch):
+    """Host logic with two leads (SNR-weighted combination, one model per (lead, cluster)): cluster_new_batch(learning=True)
+    against the reference's trace; tolerance as in tests/test_gpu_include_batch.py."""
+    from offline_trace import run_cluster_learning
+    cpu_double.install(monkeypatch)
+    g = golden("cluster_learning_r102_2leads.npz")
+    sw, tr = run_cluster_learning(g)
+    compare_trace(g, sw, tr, q_tol=max(1e-8, 50.0 * float(g["ref_sens"])))
