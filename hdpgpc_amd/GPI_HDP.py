@@ -25,7 +25,7 @@ from scipy.special import digamma as _digamma
 
 from . import hdp_global, ops
 from .GPI import RBFWhiteKernel
-from .GPI_model import GPI_model
+from .GPI_model import GPI_model, _copy_list
 from .offline_loop import OfflineLoop
 from .online_loop import OnlineLoop
 
@@ -109,7 +109,7 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         g = GPI_model(gpmodel.gp.kernel.clone_with_theta(gpmodel.gp.kernel.theta), gpmodel.x_basis.clone(), annealing=gpmodel.annealing,
                       bayesian=gpmodel.bayesian, free_deg_MNIV=gpmodel.free_deg_MNIV, verbose=self.verbose)
         for name in ("y_train", "x_train", "f_star", "f_star_sm", "cov_f", "cov_f_sm", "A", "Gamma", "C", "Sigma", "indexes"):
-            setattr(g, name, list(getattr(gpmodel, name)))
+            setattr(g, name, _copy_list(getattr(gpmodel, name)))
         g.N, g.fitted, g.ini_cov_def = gpmodel.N, gpmodel.fitted, gpmodel.ini_cov_def
         g.A_def, g.Gamma_def, g.C_def, g.Sigma_def = gpmodel.A_def, gpmodel.Gamma_def, gpmodel.C_def, gpmodel.Sigma_def
         g.internal_params, g.observation_params = gpmodel.internal_params, gpmodel.observation_params
@@ -262,13 +262,16 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         q = torch.zeros((N, M, self.n_outputs), dtype=f64, device=self.device)
         q_lat = torch.zeros_like(q)
         snr = torch.zeros_like(q)
-        self.gpmodels = [[None] * M for _ in range(self.n_outputs)]
+        # one fresh default model per (lead, class) (= the reference's deep copy of model 0 re-initialised, reinit_LDS / reinit_GP);
+        # the D x M chains are independent: they run side by side (chain_batch.py)
+        self.gpmodels = [[self.create_gp_default() for _ in range(M)] for _ in range(self.n_outputs)]
+        outs = iter(self._passes(x, y, [(self.gpmodels[ld][m], ld, resp[:, m]) for ld in range(self.n_outputs) for m in range(M)]))
         for ld in range(self.n_outputs):
             for m in range(M):
-                gp = self.create_gp_default()       # = the reference's deep copy of model 0 re-initialised (reinit_LDS / reinit_GP)
-                q[:, m, ld], q_lat[:, m, ld] = gp.full_pass_weighted(x, y[:, :, [ld]], resp[:, m])
-                snr[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
-                self.gpmodels[ld][m] = gp
+                out = next(outs)
+                if out is not None:
+                    q[:, m, ld], q_lat[:, m, ld] = out
+                snr[:, m, ld] = self.compute_snr(y[:, :, ld], self.gpmodels[ld][m])
         self.q.append(q)
         startStateCount, transStateCount = resp[0].numpy().copy(), torch.sum(respPair, dim=0).numpy()
         per_group = resp.sum(dim=0)

@@ -26,6 +26,55 @@ f64 = torch.float64
 LOG2PI = math.log(2.0 * math.pi)   # GPI_model.py:89-90
 
 
+class StackList:
+    """One per-step list of a model (f_star[i], Sigma[i], ... one entry per LDS step in the reference, a12) held as ONE stacked
+    device tensor [L, ...].  Reads behave like the reference's Python list of tensors (len, [i], [-1], slices, iteration,
+    ``+``); the first mutation (item assignment, append) turns it into a real list (copy-on-write), so a model and its
+    copies can share one.  A 2 272-step chain is 8 such lists: building 18 000 tensor objects per pass, and re-stacking
+    them for every batched kernel, was 10 % of the offline loop's wall-clock."""
+    __slots__ = ("_st", "_ls")
+
+    def __init__(self, stack):
+        self._st, self._ls = stack, None
+
+    def _list(self):
+        if self._ls is None:
+            self._ls, self._st = list(self._st.unbind(0)), None
+        return self._ls
+
+    def stack(self):
+        return self._st if self._ls is None else torch.stack(self._ls).contiguous()
+
+    def __len__(self):
+        return self._st.shape[0] if self._ls is None else len(self._ls)
+
+    def __getitem__(self, i):
+        if self._ls is not None:
+            return self._ls[i]
+        if isinstance(i, slice):
+            return list(self._st[i].unbind(0))
+        return self._st[i]
+
+    def __setitem__(self, i, v):
+        self._list()[i] = v
+
+    def append(self, v):
+        self._list().append(v)
+
+    def __iter__(self):
+        return iter(self._st.unbind(0) if self._ls is None else self._ls)
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def copy(self):
+        return StackList(self._st) if self._ls is None else list(self._ls)
+
+
+def _copy_list(lst):
+    return lst.copy() if isinstance(lst, StackList) else list(lst)
+
+
 class matrix_normal_inv_wishart:
     """GPI_model.py:1281-1298 (container) + log_likelihood_MNIW (GPI_model.py:1346-1362)."""
 
@@ -143,8 +192,12 @@ class GPI_model:
         that rewrites an entry in place resets ``_stk``)."""
         lst = getattr(self, name)
         key = self._stk.get(name)
+        if isinstance(lst, StackList) and lst._ls is None:          # already one tensor: no copy
+            if key is None or key[2] is not lst._st:
+                self._stk[name] = [len(lst), None, lst._st, None]
+            return lst._st
         if key is None or key[0] != len(lst) or key[1] is not lst[-1]:
-            self._stk[name] = [len(lst), lst[-1], torch.stack(lst).contiguous(), None]
+            self._stk[name] = [len(lst), lst[-1], torch.stack(list(lst)).contiguous(), None]
         return self._stk[name][2]
 
     def _S_symmetric(self, name):
@@ -504,8 +557,9 @@ class GPI_model:
         dev = self.device
 
         def stack(lst, shape):
-            buf = torch.zeros((L + n_more,) + shape, dtype=f64, device=dev)
-            buf[:L] = torch.stack(lst)
+            buf = torch.empty((L + n_more,) + shape, dtype=f64, device=dev)
+            buf[:L] = lst.stack() if isinstance(lst, StackList) else torch.stack(lst)
+            buf[L:].zero_()
             return buf
 
         ch = {"F": stack(self.f_star, (T, 1)), "Fsm": stack(self.f_star_sm, (T, 1)), "P": stack(self.cov_f, (T, T)),
@@ -589,7 +643,7 @@ class GPI_model:
         ops.lds_chain_finish(part, mm(e, e, transB=True), S__, i1, i2, ch["W"], n0, ch["Nf"], ch["bad"], ch["A"], ch["G"],
                              ch["C"], ch["S"], pos, self.annealing, ch["sync"], info0=i4)
 
-    def _chain_lists(self, ch):
+    def _chain_lists(self, ch, views=None):
         """The member step as ONE launch per dependency level (hgp_chain.hip): every product of the step is an item of a
         device-resident list whose pointers are fixed for the life of the chain; the two inversions carry their right-hand
         sides.  14 launches per member, no torch arithmetic, no allocation (measured: a dependent launch costs ~4.5 us
@@ -603,8 +657,10 @@ class GPI_model:
         ws = ch["ws"]
         A, G, C, S, Psm, c0 = (ws[i * tt:(i + 1) * tt].view(T, T) for i in range(6))
         m0, Fsm = ws[6 * tt:6 * tt + T], ws[6 * tt + T:]
-        X4, RH4, Z4, Y4 = new(4, T, T), new(4, T, T), new(4, T, T), new(4, T, T)    # [P, Sk, R0', R1'], their riding RHS, Z, Z rhs
-        S__, S_, Zs, Y3, part = new(2, T, T), new(2, T, T), new(2, T, T), new(2, T, T), new(2, T, T)
+        v = views or {}     # chain_batch.run hands out slices of buffers shared by many chains (one batched inversion for all)
+        X4, RH4, Z4, Y4 = (v[k] if k in v else new(4, T, T) for k in ("X4", "RH4", "Z4", "Y4"))   # [P, Sk, R0', R1'], riding RHS, Z, Z rhs
+        S__, S_, Zs, Y3 = (v[k] if k in v else new(2, T, T) for k in ("S__", "S_", "Zs", "Y3"))
+        part = new(2, T, T)
         AP0, Pk, K_t, J, SINV, IKC, KS, MS, T1, KKt, KKtmP, c_post, CmP, X, P_sm_prev = (
             new(T, T), new(T, T), new(T, T), new(T, T), new(2, T, T), new(T, T), new(T, T), new(2, T, T), new(T, T), new(T, T),
             new(T, T), new(T, T), new(T, T), new(T, T), new(T, T))
@@ -654,14 +710,15 @@ class GPI_model:
             lvy[1].add(Zs[0], S_[0], Y3[0], transB=True)         # Z_s S_^T
             lvy[1].add(Zs[1], S_[1], Y3[1], transB=True)
             lv += lvy
-        for l_ in lv:
-            l_.finalize()
+        if views is None:
+            for l_ in lv:
+                l_.finalize()
         ch["lv"], ch["riding"] = lv, riding
         ch["bufs"] = dict(X4=X4, RH4=RH4, Z4=Z4, Y4=Y4, S__=S__, S_=S_, Zs=Zs, Y3=Y3, part=part, y=y, f_post=f_post, c_post=c_post,
                           f_sm_prev=f_sm_prev, P_sm_prev=P_sm_prev)
         ch["rhs_on"] = torch.tensor([1, 1, 0, 0], dtype=torch.int32, device=dev)
-        ch["i4"] = torch.zeros(4, dtype=torch.int32, device=dev)
-        ch["i2"] = torch.zeros(2, dtype=torch.int32, device=dev)
+        ch["i4"] = v["i4"] if "i4" in v else torch.zeros(4, dtype=torch.int32, device=dev)
+        ch["i2"] = v["i2"] if "i2" in v else torch.zeros(2, dtype=torch.int32, device=dev)
 
     def _chain_step2(self, ch):
         """_chain_step with one launch per dependency level; see _chain_lists."""
@@ -689,7 +746,7 @@ class GPI_model:
 
     def _chain_commit(self, ch, members, x_trains, y_trains):
         L = int(ch["pos"][0]) + 1
-        unb = lambda k: list(ch[k][:L].unbind(0))          # noqa: E731
+        unb = lambda k: StackList(ch[k][:L])               # noqa: E731  (rows stay views of the chain's stacks)
         self.f_star, self.f_star_sm, self.cov_f, self.cov_f_sm = unb("F"), unb("Fsm"), unb("P"), unb("Psm")
         self.A, self.Gamma, self.C, self.Sigma = unb("A"), unb("G"), unb("C"), unb("S")
         n0 = float(ch["n0"])
@@ -742,10 +799,9 @@ class GPI_model:
         L = len(self.f_star)
         if L - 1 < 2:
             return self.backwards()
-        M = torch.stack(self.f_star[1:]).contiguous()
-        Cv = torch.stack(self.cov_f[1:]).contiguous()
-        A = torch.stack(self.A[1:]).contiguous()
-        G = torch.stack(self.Gamma[1:]).contiguous()
+        st = lambda lst: (lst.stack() if isinstance(lst, StackList) else torch.stack(lst))[1:]     # noqa: E731
+        M, Cv = st(self.f_star).clone(), st(self.cov_f).clone()          # smoothed in place below: the filtered lists stay
+        A, G = st(self.A).contiguous(), st(self.Gamma).contiguous()
         nA, n = A.shape[0], M.shape[0]
         # Everything that only reads the FILTERED states is batched over all steps at once (GPI.py:252-262 uses the
         # filtered cov_t for P_t and the gain J_t): P_t = A_t c_t A_t^T + G_t, its inverse, J_t = c_t A_t^T P_t^{-1} and
@@ -764,9 +820,8 @@ class GPI_model:
             self._check_pending()
             Mv = M.reshape(n, -1)
             ops.rts_chain(Jb, Pb, AMb.reshape(n - 1, -1).contiguous(), Mv, Cv)
-            for i in range(n):
-                self.f_star_sm[i + 1] = M[i]
-                self.cov_f_sm[i + 1] = Cv[i]
+            self.f_star_sm = StackList(torch.cat([self.f_star_sm[0].unsqueeze(0), M]))
+            self.cov_f_sm = StackList(torch.cat([self.cov_f_sm[0].unsqueeze(0), Cv]))
             self._stk = {}
             return
         # T > 96: the two-line recursion as product lists (hgp_gemm_list_f64), two dependent launches per step and no other

@@ -54,9 +54,12 @@ def _load():
         "hgp_assign_f64": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "hgp_warp_batch_f64": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp, vp, vp]),
         "hgp_gemm_list_f64": (i32, [vp, i32, i32, vp]),
+        "hgp_gemm_list_mapped_f64": (i32, [vp, i32, vp, i32, vp]),
         "hgp_chol_inverse_rhs_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, i32, vp, vp, vp]),
         "hgp_lds_chain_gather2_f64": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, vp, vp, vp, vp]),
         "hgp_lds_chain_finish2_f64": (i32, [i32] + [vp] * 22 + [i32, vp, vp]),
+        "hgp_lds_chain_gather2_batched_f64": (i32, [vp, i32, i32, vp]),
+        "hgp_lds_chain_finish2_batched_f64": (i32, [vp, i32, i32, vp]),
         "hgp_trsv_lower_solve_f64": (i32, [vp, i32, vp, i32, vp, vp, vp]),
         "hgp_lml_grad_f64": (i32, [vp, vp, vp, i32, f64, f64, f64, vp, vp]),
     }
@@ -76,6 +79,20 @@ class GemmItem(ctypes.Structure):
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int),
                 ("ldc", ctypes.c_int), ("ldd", ctypes.c_int), ("tA", ctypes.c_int), ("tB", ctypes.c_int),
                 ("alpha", ctypes.c_double), ("beta", ctypes.c_double), ("add_eye", ctypes.c_double)]
+
+
+class ChainGatherDesc(ctypes.Structure):
+    """hgp_chain_gather_desc of include/hdpgpc_hip.h."""
+    _fields_ = [("st", ctypes.c_void_p * 8), ("pos", ctypes.c_void_p), ("out", ctypes.c_void_p), ("Y", ctypes.c_void_p),
+                ("y_out", ctypes.c_void_p), ("W", ctypes.c_void_p), ("Rp", ctypes.c_void_p), ("y_row0", ctypes.c_long),
+                ("T", ctypes.c_int)]
+
+
+class ChainFinishDesc(ctypes.Structure):
+    """hgp_chain_finish_desc of include/hdpgpc_hip.h."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("f_post", "c_post", "f_sm_prev", "P_sm_prev", "y", "part", "Snew", "info1", "info2", "W",
+                                               "n0", "Nf", "bad_count", "stA", "stG", "stC", "stS", "stF", "stFsm", "stP", "stPsm", "pos",
+                                               "sync")] + [("T", ctypes.c_int), ("annealing", ctypes.c_int)]
 
 
 class HgpError(RuntimeError):

@@ -22,17 +22,28 @@ using namespace hgp;
 namespace {
 
 // -------------------------------------------------------------------------------------------- list GEMM
-__global__ __launch_bounds__(64 * WAVES) void k_gemm_list(const hgp_gemm_item* __restrict__ items, int n_items) {
+// tile_map (may be NULL): tile_map[t] = (item << 16) | tile-within-item for the t-th output tile of the list.  Without it a
+// wave finds its item by walking the list - one dependent global load per item, fine for the 1-5 items of one chain's level,
+// 25 us for the 50 items of ten chains side by side.
+__global__ __launch_bounds__(64 * WAVES) void k_gemm_list(const hgp_gemm_item* __restrict__ items, int n_items,
+                                                          const uint32_t* __restrict__ tile_map, int total_tiles) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
   int tile = blockIdx.x * WAVES + wave;
   int it = 0;
-  for (; it < n_items; ++it) {           // which item does this wave's tile belong to?
-    const int nt = ((items[it].M + 15) >> 4) * ((items[it].N + 15) >> 4);
-    if (tile < nt) break;
-    tile -= nt;
+  if (tile_map) {
+    if (tile >= total_tiles) return;
+    const uint32_t e = tile_map[tile];
+    it = (int)(e >> 16);
+    tile = (int)(e & 0xffffu);
+  } else {
+    for (; it < n_items; ++it) {           // which item does this wave's tile belong to?
+      const int nt = ((items[it].M + 15) >> 4) * ((items[it].N + 15) >> 4);
+      if (tile < nt) break;
+      tile -= nt;
+    }
+    if (it >= n_items) return;
   }
-  if (it >= n_items) return;
   const hgp_gemm_item q = items[it];
   const int ntn = (q.N + 15) >> 4;
   const int ti = tile / ntn, tj = tile % ntn;
@@ -144,20 +155,9 @@ void launch_inv_rhs(const InvRhsArgs& a, hipStream_t st) {
 // -------------------------------------------------------------------------------------------- fused glue of the step
 // gather (rows `pos` of the stacks -> workspace, the member's observation) + the jittered right covariances of the two MNIW
 // updates  R' = R + 1e-2 max(mean |diag scale|, eps) I  (GPI_model.py:1312-1316), one launch.
-struct Gather2Args {
-  const double* st[8];   // A, G, C, S, Psm, P (T*T each), F, Fsm (T each)
-  const int64_t* pos;
-  double* out;           // [6 T T + 2 T]
-  int T;
-  const double* Y;
-  long y_row0;
-  double* y_out;
-  const double* W;       // [3,2,T,T] means, R, scales
-  double* Rp;            // [2,T,T]
-};
+using Gather2Args = hgp_chain_gather_desc;   // include/hdpgpc_hip.h
 
-__global__ __launch_bounds__(256) void k_chain_gather2(Gather2Args a) {
-  __shared__ double red[2][4];
+__device__ __forceinline__ void chain_gather2_body(const Gather2Args& a, double (&red)[2][4]) {
   const long tt = (long)a.T * a.T, p = a.pos[0];
   const long total = 6 * tt + 2 * a.T;
   // mean |diag scale| of both MNIW distributions, by every block (2 T strided loads, one LDS reduction)
@@ -200,34 +200,25 @@ __global__ __launch_bounds__(256) void k_chain_gather2(Gather2Args a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_chain_gather2(Gather2Args a) {
+  __shared__ double red[2][4];
+  chain_gather2_body(a, red);
+}
+
+// the same for a BATCH of independent chains: blockIdx.y = chain, one descriptor per chain in device memory
+__global__ __launch_bounds__(256) void k_chain_gather2_b(const Gather2Args* __restrict__ descs) {
+  __shared__ double red[2][4];
+  const Gather2Args a = descs[blockIdx.y];
+  chain_gather2_body(a, red);
+}
+
 // scatter + finish: append the new filtered state, overwrite the re-smoothed previous one (GPI_model.py:317,705-716), the
 // element-wise tail of both MNIW updates with (y1 - y2)(y1 - y2)^T formed here, the annealed scales, the append of
 // A, Gamma, C, Sigma and the counters (GPI_model.py:1068-1106,1326-1336).
-struct Finish2Args {
-  int T;
-  const double* f_post;      // [T]
-  const double* c_post;      // [T,T]
-  const double* f_sm_prev;   // [T]
-  const double* P_sm_prev;   // [T,T]
-  const double* y;           // [T] the member's observation
-  const double* part;        // [2,T,T]
-  const double* Snew;        // [2,T,T]
-  const int32_t* info1;      // [4] first inversion: (P, S_k, R0', R1')
-  const int32_t* info2;      // [2] second inversion
-  double* W;                 // [3,2,T,T]
-  double* n0;
-  double* Nf;
-  int32_t* bad_count;        // [2]
-  double* stA; double* stG; double* stC; double* stS;
-  double* stF; double* stFsm; double* stP; double* stPsm;
-  int64_t* pos;
-  int annealing;
-  int32_t* sync;
-};
+using Finish2Args = hgp_chain_finish_desc;   // include/hdpgpc_hip.h
 
 #pragma clang fp contract(off)   // the reference's op order, no fused multiply-adds
-__global__ __launch_bounds__(256) void k_chain_finish2(Finish2Args a) {
-  __shared__ int last;
+__device__ __forceinline__ void chain_finish2_body(const Finish2Args& a, int& last) {
   const int T = a.T;
   const long tt = (long)T * T;
   const bool bad = (a.info1[2] | a.info1[3] | a.info2[0] | a.info2[1]) != 0;
@@ -282,6 +273,17 @@ __global__ __launch_bounds__(256) void k_chain_finish2(Finish2Args a) {
     a.sync[0] = 0;
   }
 }
+
+__global__ __launch_bounds__(256) void k_chain_finish2(Finish2Args a) {
+  __shared__ int last;
+  chain_finish2_body(a, last);
+}
+
+__global__ __launch_bounds__(256) void k_chain_finish2_b(const Finish2Args* __restrict__ descs) {
+  __shared__ int last;
+  const Finish2Args a = descs[blockIdx.y];
+  chain_finish2_body(a, last);
+}
 #pragma clang fp contract(on)
 
 }  // namespace
@@ -291,7 +293,16 @@ extern "C" {
 int hgp_gemm_list_f64(const hgp_gemm_item* items_dev, int n_items, int total_tiles, void* stream) {
   if (n_items == 0) return 0;
   if (!items_dev || n_items < 0 || total_tiles <= 0) return -1;
-  hipLaunchKernelGGL(k_gemm_list, dim3((total_tiles + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream, items_dev, n_items);
+  hipLaunchKernelGGL(k_gemm_list, dim3((total_tiles + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream, items_dev, n_items,
+                     (const uint32_t*)nullptr, total_tiles);
+  return launch_status();
+}
+
+int hgp_gemm_list_mapped_f64(const hgp_gemm_item* items_dev, int n_items, const uint32_t* tile_map_dev, int total_tiles, void* stream) {
+  if (n_items == 0) return 0;
+  if (!items_dev || !tile_map_dev || n_items < 0 || n_items > 65535 || total_tiles <= 0) return -1;
+  hipLaunchKernelGGL(k_gemm_list, dim3((total_tiles + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, (hipStream_t)stream, items_dev, n_items,
+                     tile_map_dev, total_tiles);
   return launch_status();
 }
 
@@ -315,7 +326,7 @@ int hgp_lds_chain_gather2_f64(const double* stA, const double* stG, const double
                               const double* stP, const double* stF, const double* stFsm, const int64_t* pos, int T, double* out,
                               const double* Y, long y_row0, double* y_out, const double* W, double* Rp, void* stream) {
   if (!stA || !stG || !stC || !stS || !stP || !stPsm || !stF || !stFsm || !pos || !out || !W || !Rp || T <= 0 || (Y && !y_out)) return -1;
-  Gather2Args a{{stA, stG, stC, stS, stPsm, stP, stF, stFsm}, pos, out, T, Y, y_row0, y_out, W, Rp};
+  Gather2Args a{{stA, stG, stC, stS, stPsm, stP, stF, stFsm}, pos, out, Y, y_out, W, Rp, y_row0, T};
   const long total = 8L * T * T + 2L * T;
   hipLaunchKernelGGL(k_chain_gather2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
@@ -329,10 +340,27 @@ int hgp_lds_chain_finish2_f64(int T, const double* f_post, const double* c_post,
   if (!f_post || !c_post || !f_sm_prev || !P_sm_prev || !y || !part || !Snew || !info1 || !info2 || !W || !n0 || !Nf || !bad_count ||
       !stA || !stG || !stC || !stS || !stF || !stFsm || !stP || !stPsm || !pos || !sync || T <= 0)
     return -1;
-  Finish2Args a{T, f_post, c_post, f_sm_prev, P_sm_prev, y, part, Snew, info1, info2, W, n0, Nf, bad_count,
-                stA, stG, stC, stS, stF, stFsm, stP, stPsm, pos, annealing, sync};
+  Finish2Args a{f_post, c_post, f_sm_prev, P_sm_prev, y, part, Snew, info1, info2, W, n0, Nf, bad_count,
+                stA, stG, stC, stS, stF, stFsm, stP, stPsm, pos, sync, T, annealing};
   const long n2 = 2L * T * T;
   hipLaunchKernelGGL(k_chain_finish2, dim3((unsigned)std::min<long>(64, (n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int hgp_lds_chain_gather2_batched_f64(const hgp_chain_gather_desc* descs_dev, int n_chains, int T, void* stream) {
+  if (n_chains == 0) return 0;
+  if (!descs_dev || n_chains < 0 || T <= 0) return -1;
+  const long total = 8L * T * T + 2L * T;
+  hipLaunchKernelGGL(k_chain_gather2_b, dim3((unsigned)((total + 255) / 256), (unsigned)n_chains), dim3(256), 0, (hipStream_t)stream, descs_dev);
+  return launch_status();
+}
+
+int hgp_lds_chain_finish2_batched_f64(const hgp_chain_finish_desc* descs_dev, int n_chains, int T, void* stream) {
+  if (n_chains == 0) return 0;
+  if (!descs_dev || n_chains < 0 || T <= 0) return -1;
+  const long n2 = 2L * T * T;
+  hipLaunchKernelGGL(k_chain_finish2_b, dim3((unsigned)std::min<long>(64, (n2 + 255) / 256), (unsigned)n_chains), dim3(256), 0,
+                     (hipStream_t)stream, descs_dev);
   return launch_status();
 }
 

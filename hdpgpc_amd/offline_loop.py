@@ -22,7 +22,7 @@ with ``warp=False`` the reference's 4-D ``y_trains_w`` is a broadcast view of ``
 import numpy as np
 import torch
 
-from . import hdp_global, ops
+from . import chain_batch, hdp_global, ops
 
 f64 = torch.float64
 
@@ -291,38 +291,44 @@ class OfflineLoop:
         reorder = torch.argsort(self._counts(resp_temp), descending=True)
         resp_temp = resp_temp[:, reorder].clone()                              # quirk: the pair table keeps the old order
         gpmodels_temp = [[] for _ in range(D)]
+        plan = []                                     # (ld, m, r, model, kind): kind 0 unchanged, 1 changed, 2 new with members, 3 new empty
         for ld in range(D):
             for m in range(M):
                 r = int(reorder[m])
                 members = torch.where(resp_temp[:, m] == 1.0)[0].tolist()
                 if len(gpmodels[ld]) > r:
                     gp = gpmodels[ld][r]
+                    kind = 0
                     if members != [int(i) for i in gp.indexes]:
+                        kind = 1
                         if gp.fitted:
-                            src = gp
-                            gp = self.gpmodel_deepcopy(src)
+                            gp = self.gpmodel_deepcopy(gp)
                             gp.reinit_LDS(save_last=not reparam)
                             gp.reinit_GP(save_last=False)
                         else:
                             gp = self.create_gp_default(i=r)
-                        q[:, m, ld], q_lat[:, m, ld] = self._full_pass(gp, x_trains, y_trains, ld, resp_temp[:, m],
-                                                                      q_[:, r, ld], q_lat_[:, r, ld])
-                        snr_aux[:, m, ld] = self.compute_snr(y_trains[:, :, ld], gp)
-                    else:
-                        q[:, m, ld] = q_[:, r, ld]
-                        q_lat[:, m, ld] = q_lat_[:, r, ld]
-                        snr_aux[:, m, ld] = snr_[:, m, ld].clone()             # quirk: column m, not r
                 else:
                     gp = self.create_gp_default(i=r)
-                    if len(members) > 0:
-                        q[:, m, ld], q_lat[:, m, ld] = self._full_pass(gp, x_trains, y_trains, ld, resp_temp[:, m],
-                                                                      q_[:, r, ld], q_lat[:, r, ld])
-                        snr_aux[:, m, ld] = self.compute_snr(y_trains[:, :, ld], gp)
-                    else:
-                        q[:, m, ld] = q_[:, m, ld]
-                        q_lat[:, m, ld] = q_lat_[:, m, ld]
-                        snr_aux[:, m, ld] = 0.0
+                    kind = 2 if len(members) > 0 else 3
+                plan.append((ld, m, r, gp, kind))
                 gpmodels_temp[ld].append(gp)
+        outs = iter(self._passes(x_trains, y_trains, [(gp, ld, resp_temp[:, m]) for ld, m, r, gp, kind in plan if kind in (1, 2)]))
+        for ld, m, r, gp, kind in plan:
+            if kind in (1, 2):
+                out = next(outs)
+                self._note_full_pass(resp_temp[:, m], out)
+                if out is None:                       # no members: the previous columns (quirk: of the table being filled, for q_lat of a new model)
+                    out = (q_[:, r, ld], (q_lat_ if kind == 1 else q_lat)[:, r, ld])
+                q[:, m, ld], q_lat[:, m, ld] = out
+                snr_aux[:, m, ld] = self.compute_snr(y_trains[:, :, ld], gp)
+            elif kind == 0:
+                q[:, m, ld] = q_[:, r, ld]
+                q_lat[:, m, ld] = q_lat_[:, r, ld]
+                snr_aux[:, m, ld] = snr_[:, m, ld].clone()                     # quirk: column m, not r
+            else:
+                q[:, m, ld] = q_[:, m, ld]
+                q_lat[:, m, ld] = q_lat_[:, m, ld]
+                snr_aux[:, m, ld] = 0.0
         self._log(">>> Q_all_loop -------")
         q_bas, elbo_bas = self._elbo_of(resp, respPair, q_, q_lat_, snr_, gpmodels, self.M, post)
         q_bas_post, elbo_post = self._elbo_of(resp_temp, respPair_temp, q, q_lat, snr_aux, gpmodels_temp, M, post)
@@ -347,10 +353,16 @@ class OfflineLoop:
         self._log("Bad estimation")
         return resp, respPair, q_, q_lat_, snr_, gpmodels
 
-    def _full_pass(self, gp, x, y, ld, resp_col, q_prev, q_lat_prev):
-        """gp.full_pass_weighted on lead ld; a cluster without members hands back the previous columns (GPI_model.py:385-386)."""
-        out = gp.full_pass_weighted(x, y[:, :, [ld]], resp_col, q=q_prev, q_lat=q_lat_prev)
-        return out[0], out[1]
+    def _passes(self, x, y, specs):
+        """full_pass_weighted of many (model, lead, membership column) at once: the chains do not depend on each other, so they
+        advance side by side (chain_batch.py).  Returns per spec (q, q_lat), or None for a cluster without members (the caller
+        keeps its previous columns, GPI_model.py:385-386).  ``_note_full_pass`` sees every result in spec order."""
+        jobs = [chain_batch.Job(gp, x, y[:, :, [ld]], col) for gp, ld, col in specs]
+        chain_batch.run(jobs)
+        return [j.out if len(j.active) else None for j in jobs]
+
+    def _note_full_pass(self, resp_col, out):
+        """Hook (tests): called once per full pass, in the order the reference's loop makes them."""
 
     def _elbo_of(self, resp, respPair, q, q_lat, snr, gpmodels, M, post):
         return self.compute_q_elbo(resp, respPair, self.weight_mean(q, snr), self.weight_mean(q_lat, snr), gpmodels, M,
@@ -382,14 +394,14 @@ class OfflineLoop:
         empty_estimation = False
         if float(torch.mean(q_)) == 0.0:                     # nothing scored yet: cluster 0 takes the whole batch
             snr_ = torch.zeros((N, M, D), dtype=f64, device=dev)
-            for ld in range(D):
-                if not self.share_gp or ld == 0:
-                    gp = self.create_gp_default()
-                else:
-                    gp = self._fresh_copy(self.gpmodels[ld - 1][0])
-                q_[:, 0, ld], q_lat_[:, 0, ld] = self._full_pass(gp, x, y, ld, resp[:, 0], None, None)
-                snr_[:, 0, ld] = self.compute_snr(y[:, :, ld], gp)
-                self.gpmodels[ld][0] = gp
+            if self.share_gp and D > 1:
+                raise NotImplementedError("share_gp with several leads is not part of this build")
+            firsts = [self.create_gp_default() for _ in range(D)]
+            for ld, out in enumerate(self._passes(x, y, [(firsts[ld], ld, resp[:, 0]) for ld in range(D)])):
+                self._note_full_pass(resp[:, 0], out)
+                q_[:, 0, ld], q_lat_[:, 0, ld] = out
+                snr_[:, 0, ld] = self.compute_snr(y[:, :, ld], firsts[ld])
+                self.gpmodels[ld][0] = firsts[ld]
         reallocate = False
         indexes_ = []
         for m in range(M):
@@ -414,18 +426,24 @@ class OfflineLoop:
             resp_temp = resp_temp[:, reorder]
             q, q_lat = q_.clone(), q_lat_.clone()
             gpmodels_temp = [[] for _ in range(D)]
+            plan = []
             for ld in range(D):
                 for m in range(M):
                     r = int(reorder[m])
-                    if not torch.equal(resp[:, r].long(), resp_temp[:, m].long()):
-                        gp = self._fresh_copy(self.gpmodels[ld][r])
-                        q[:, m, ld], q_lat[:, m, ld] = self._full_pass(gp, x, y, ld, resp_temp[:, m], q[:, r, ld], q_lat[:, r, ld])
-                        snr_aux[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
-                    else:
-                        gp = self.gpmodels[ld][r]
-                        q[:, m, ld] = q_[:, r, ld].clone()                    # quirk: q_lat keeps column m of the old table
-                        snr_aux[:, m, ld] = snr_[:, r, ld].clone()
+                    changed = not torch.equal(resp[:, r].long(), resp_temp[:, m].long())
+                    gp = self._fresh_copy(self.gpmodels[ld][r]) if changed else self.gpmodels[ld][r]
+                    plan.append((ld, m, r, gp, changed))
                     gpmodels_temp[ld].append(gp)
+            outs = iter(self._passes(x, y, [(gp, ld, resp_temp[:, m]) for ld, m, r, gp, changed in plan if changed]))
+            for ld, m, r, gp, changed in plan:
+                if changed:
+                    out = next(outs)
+                    self._note_full_pass(resp_temp[:, m], out)
+                    q[:, m, ld], q_lat[:, m, ld] = out if out is not None else (q[:, r, ld], q_lat[:, r, ld])
+                    snr_aux[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
+                else:
+                    q[:, m, ld] = q_[:, r, ld].clone()                    # quirk: q_lat keeps column m of the old table
+                    snr_aux[:, m, ld] = snr_[:, r, ld].clone()
             q_b, e_b = self._elbo_of(resp_temp, respPair_temp, q, q_lat, snr_aux, gpmodels_temp, M, False)
             q_def__, elbo_def__ = self._elbo_of(resp, respPair, q_, q_lat_, snr_, self.gpmodels, M, False)
             resp_temp, respPair_temp, q, q_lat, snr_aux, gpmodels_temp, base_ = self._converge(
@@ -505,7 +523,11 @@ class OfflineLoop:
         M = M + 1
         f_ind_old = torch.zeros(M, dtype=torch.int64)
         f_ind_old[:self.f_ind_old.shape[0]] = self.f_ind_old
-        f_ind_old_temp, q_simple_ = None, None
+        # The candidates of one round do not depend on each other's outcome (the reference tries them one by one and stops at the
+        # first it accepts; nothing it computes for candidate j feeds candidate j + 1).  They are therefore PREPARED together
+        # (host logic + one one-member score and one message pass each), all the cluster rebuilds they need run side by side as
+        # one batch of independent chains, and the accept / reject decisions are then taken in the reference's order.
+        props = []
         step, last = 0, {-1}
         for f_new in seeds.tolist():
             if step == n_steps:
@@ -513,9 +535,10 @@ class OfflineLoop:
             m_chosen = cluster_of(f_new, M - 1)
             if f_new == int(f_ind_old[m_chosen]) or last <= near(f_new):
                 continue
+            P = {"f_new": f_new, "m_chosen": m_chosen, "f_ind_old_temp": None, "q_simple_": None}
             if not empty_estimation:
-                f_ind_old_temp = f_ind_old.clone()
-                f_ind_old_temp[-1] = f_new
+                P["f_ind_old_temp"] = f_ind_old.clone()
+                P["f_ind_old_temp"][-1] = f_new
                 q_simple_ = q_def.clone()
                 q, q_lat, snr_aux = q_def.clone(), q_lat_def.clone(), snr_aux_def.clone()
                 q__, q_lat__, snr__ = q__def.clone(), q_lat__def.clone(), snr__def.clone()
@@ -525,6 +548,7 @@ class OfflineLoop:
                 for ld in range(D):
                     q_simple_[:, -1, ld], g1 = self._one_member_scores(self.gpmodels[ld][m_chosen], x, y, ld, f_new)
                     snr_aux[:, -1, ld] = self.compute_snr(y[:, :, ld], g1)
+                P["q_simple_"] = q_simple_
                 resp_temp, respPair_temp = self._assign(self.weight_mean(q_simple_, snr_aux), startPi)
             else:
                 q, q_lat, snr_aux = q__def.clone(), q_lat__def.clone(), snr__def.clone()
@@ -537,6 +561,7 @@ class OfflineLoop:
             reorder = torch.argsort(self._counts(resp_temp), descending=True)
             resp_temp = resp_temp[:, reorder]
             gpmodels_temp = [[] for _ in range(D)]
+            plan = []
             for ld in range(D):
                 for m in range(M):
                     r = int(reorder[m])
@@ -546,14 +571,32 @@ class OfflineLoop:
                     else:
                         rebuild = not torch.equal(resp[:, r].long(), resp_temp[:, m].long())
                         gp = self._fresh_copy(self.gpmodels[ld][r]) if rebuild else self.gpmodels[ld][r]
-                    if rebuild:
-                        q[:, m, ld], q_lat[:, m, ld] = self._full_pass(gp, x, y, ld, resp_temp[:, m], q__[:, r, ld], q_lat__[:, r, ld])
-                        snr_aux[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
-                    else:
-                        q[:, m, ld] = q__[:, r, ld].clone()
-                        q_lat[:, m, ld] = q_lat__[:, r, ld].clone()
-                        snr_aux[:, m, ld] = snr__[:, r, ld].clone()
+                    plan.append((ld, m, r, gp, rebuild))
                     gpmodels_temp[ld].append(gp)
+            P.update(q=q, q_lat=q_lat, snr_aux=snr_aux, q__=q__, q_lat__=q_lat__, snr__=snr__, resp_temp=resp_temp,
+                     respPair_temp=respPair_temp, reorder=reorder, gpmodels_temp=gpmodels_temp, plan=plan)
+            props.append(P)
+        # ... in two batches: the first candidate alone (it is the one most often accepted), then all the others.
+        def rebuilds(ps):
+            return iter(self._passes(x, y, [(gp, ld, P["resp_temp"][:, m]) for P in ps for ld, m, r, gp, rebuild in P["plan"] if rebuild]))
+
+        outs = None
+        for ip, P in enumerate(props):
+            if ip < 2:
+                outs = rebuilds(props[:1] if ip == 0 else props[1:])
+            f_new, m_chosen, q_simple_, f_ind_old_temp = P["f_new"], P["m_chosen"], P["q_simple_"], P["f_ind_old_temp"]
+            q, q_lat, snr_aux, q__, q_lat__, snr__ = P["q"], P["q_lat"], P["snr_aux"], P["q__"], P["q_lat__"], P["snr__"]
+            resp_temp, respPair_temp, reorder, gpmodels_temp = P["resp_temp"], P["respPair_temp"], P["reorder"], P["gpmodels_temp"]
+            for ld, m, r, gp, rebuild in P["plan"]:
+                if rebuild:
+                    out = next(outs)
+                    self._note_full_pass(resp_temp[:, m], out)
+                    q[:, m, ld], q_lat[:, m, ld] = out if out is not None else (q__[:, r, ld], q_lat__[:, r, ld])
+                    snr_aux[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
+                else:
+                    q[:, m, ld] = q__[:, r, ld].clone()
+                    q_lat[:, m, ld] = q_lat__[:, r, ld].clone()
+                    snr_aux[:, m, ld] = snr__[:, r, ld].clone()
             q_b, e_b = self._elbo_of(resp_temp, respPair_temp, q, q_lat, snr_aux, gpmodels_temp, M, True)
             counts_t = self._counts(resp_temp)
             if int(torch.argmax(counts_t)) == M - 1:
@@ -752,13 +795,15 @@ class OfflineLoop:
         resp = resp[:, reorder]                                                # quirk: the pair table keeps the old order
         q = torch.zeros((N, self.M, D), dtype=f64, device=dev)
         q_lat, snr = torch.zeros_like(q), torch.zeros_like(q)
-        models = [[] for _ in range(D)]
+        models = [[self._fresh_copy(self.gpmodels[ld][int(reorder[m])]) for m in range(self.M)] for ld in range(D)]
+        outs = iter(self._passes(x, y, [(models[ld][m], ld, resp[:, m]) for ld in range(D) for m in range(self.M)]))
         for ld in range(D):
             for m in range(self.M):
-                gp = self._fresh_copy(self.gpmodels[ld][int(reorder[m])])
-                q[:, m, ld], q_lat[:, m, ld] = self._full_pass(gp, x, y, ld, resp[:, m], None, None)
-                snr[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
-                models[ld].append(gp)
+                out = next(outs)
+                self._note_full_pass(resp[:, m], out)
+                if out is not None:
+                    q[:, m, ld], q_lat[:, m, ld] = out
+                snr[:, m, ld] = self.compute_snr(y[:, :, ld], models[ld][m])
         self.gpmodels = models
         resp, respPair = self._assign(self.weight_mean(q, snr), startPi)
         self.x_train = x

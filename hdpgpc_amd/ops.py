@@ -398,14 +398,16 @@ class GemmList:
     def __init__(self, device):
         self.device = device
         self._items, self._keep, self.tiles, self._item_tiles = [], [], 0, []
-        self._dev = None
+        self._dev = self._map = None
 
     @staticmethod
     def _dims(t):
         if t.dim() == 1:
+            if t.numel() > 1 and t.stride(0) != 1:
+                raise ValueError("gemm list vectors must be contiguous (a strided 1-D view would be read as a column of stride 1)")
             return t.shape[0], 1, 1
-        if t.stride(-1) != 1:
-            raise ValueError("gemm list operands must have unit inner stride")
+        if t.stride(-1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+            raise ValueError("gemm list operands must have unit inner stride and non-overlapping rows")
         return t.shape[0], t.shape[1], t.stride(0)
 
     def add(self, A, B, out, D=None, transA=False, transB=False, alpha=1.0, beta=1.0, add_eye=0.0, out2=None):
@@ -436,11 +438,27 @@ class GemmList:
         self._dev = None
         return out
 
+    @classmethod
+    def concat(cls, lists):
+        """One list holding the items of several lists, in order (chain_batch: one launch per level for many chains)."""
+        out = cls(lists[0].device)
+        for l_ in lists:
+            out._items += l_._items
+            out._keep += l_._keep
+            out._item_tiles += l_._item_tiles
+            out.tiles += l_.tiles
+        return out
+
     def finalize(self):
         import numpy as np
         arr = (_ffi.GemmItem * len(self._items))(*self._items)
         host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
         self._dev = host.to(self.device)
+        self._map = None
+        if len(self._items) > 8:            # long lists: per-tile map instead of the per-wave walk over the items
+            m = np.concatenate([(i << 16) | np.arange(n, dtype=np.uint32) for i, n in enumerate(self._item_tiles)]).astype(np.uint32)
+            self._map = torch.from_numpy(m.view(np.int32)).to(self.device)
+            self._cum = np.concatenate([[0], np.cumsum(self._item_tiles)])
         return self
 
     def run(self):
@@ -452,6 +470,10 @@ class GemmList:
         """One launch over the items [first, first + count) of the list (a long list holding the levels of many steps)."""
         if self._dev is None:
             self.finalize()
+        if self._map is not None and first == 0:
+            _ffi.check(_ffi.lib.hgp_gemm_list_mapped_f64(_ptr(self._dev), int(count), _ptr(self._map), int(self._cum[count]), _stream()),
+                       "gemm_list_mapped")
+            return
         base = ctypes.c_void_p(self._dev.data_ptr() + first * ctypes.sizeof(_ffi.GemmItem))
         _ffi.check(_ffi.lib.hgp_gemm_list_f64(base, int(count), sum(self._item_tiles[first:first + count]), _stream()), "gemm_list")
 

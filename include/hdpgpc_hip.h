@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HGP_ABI_VERSION 3   /* 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path), assignment tail, warp fit, member-step lists */
+#define HGP_ABI_VERSION 4   /* 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path), assignment tail, warp fit, member-step lists; 4: + batched chain gather / finish */
 /* largest T (basis length) and T* (segment length) served by the register-resident wave kernels */
 #define HGP_MAX_T_WAVE 128
 /* largest T served at all: 128 < T <= 256 runs on cooperative kernels (one workgroup of 4-8 waves per matrix / pair) */
@@ -224,6 +224,10 @@ typedef struct hgp_gemm_item {
   double alpha, beta, add_eye;
 } hgp_gemm_item;
 int hgp_gemm_list_f64(const hgp_gemm_item* items_dev, int n_items, int total_tiles, void* stream);
+/* The same with a tile map in device memory, tile_map[t] = (item << 16) | tile-within-item for every output tile of the list in
+ * order: long lists (the levels of many chains side by side) without the per-wave walk over the items.  A prefix of the map
+ * (total_tiles = tiles of the first k items) runs the first k items. */
+int hgp_gemm_list_mapped_f64(const hgp_gemm_item* items_dev, int n_items, const uint32_t* tile_map_dev, int total_tiles, void* stream);
 /* Cholesky inverse with the right-hand sides riding the factorisation (T <= 128): for every matrix of the batch
  *   L = chol(0.5 (A + A^T) + shift I);  Linv = L^-1 (may be NULL);  rhs_out = L^-1 op(rhs)  (rhs NULL: none; rhs_on[m] == 0: not for m)
  * so that  B^T A^-1 = rhs_out^T Linv  costs ONE product after the factorisation (GPI.py:144-145,295; GPI_model.py:1329-1330). */
@@ -240,6 +244,33 @@ int hgp_lds_chain_finish2_f64(int T, const double* f_post, const double* c_post,
                               double* W, double* n0, double* Nf, int32_t* bad_count, double* stA, double* stG, double* stC, double* stS,
                               double* stF, double* stFsm, double* stP, double* stPsm, int64_t* pos, int annealing, int32_t* sync,
                               void* stream);
+/* The same two launches for a BATCH of independent chains (clusters x leads x proposals of the variational loop: the recursion
+ * is sequential per chain, so throughput comes from running many chains side by side): one descriptor per chain in DEVICE
+ * memory, blockIdx.y = chain.  Field meaning as the arguments of the single-chain calls above. */
+typedef struct hgp_chain_gather_desc {
+  const double* st[8];   /* stacks A, G, C, S, Psm, P ([L,T,T]), F, Fsm ([L,T]) */
+  const int64_t* pos;
+  double* out;           /* [6 T T + 2 T] */
+  const double* Y;       /* observations of the run, row pos - y_row0 is read */
+  double* y_out;
+  const double* W;       /* [3,2,T,T] means, right covariances, scales of the two MNIW distributions */
+  double* Rp;            /* [2,T,T] */
+  long y_row0;
+  int T;
+} hgp_chain_gather_desc;
+typedef struct hgp_chain_finish_desc {
+  const double* f_post; const double* c_post; const double* f_sm_prev; const double* P_sm_prev; const double* y;
+  const double* part; const double* Snew;
+  const int32_t* info1; const int32_t* info2;
+  double* W; double* n0; double* Nf;
+  int32_t* bad_count;
+  double* stA; double* stG; double* stC; double* stS; double* stF; double* stFsm; double* stP; double* stPsm;
+  int64_t* pos;
+  int32_t* sync;
+  int T, annealing;
+} hgp_chain_finish_desc;
+int hgp_lds_chain_gather2_batched_f64(const hgp_chain_gather_desc* descs_dev, int n_chains, int T, void* stream);
+int hgp_lds_chain_finish2_batched_f64(const hgp_chain_finish_desc* descs_dev, int n_chains, int T, void* stream);
 /* a10 helper - || G^{-1} y ||^2 for the lower triangle G of a [T, ld] matrix.  IterativeGaussianProcess.
  * log_marginal_likelihood as written passes K itself as the "factor" to cho_solve (GPI.py:1043); this reproduces
  * that call with G = tril(K).  out[1]. */

@@ -157,6 +157,8 @@ def install(monkeypatch):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(H.GPI_HDP, "_default_device", "cpu")
     torch.set_num_threads(1)                # 90 x 90 products: one thread is 10x faster than eight
+    from hdpgpc_amd import chain_batch
+    monkeypatch.setattr(chain_batch, "_graphable", lambda job: False)      # no hipGraph chains on the CPU: one pass after the other
     real = GM.GPI_model.full_pass_weighted
     monkeypatch.setattr(GM.GPI_model, "full_pass_weighted",
                         lambda self, x, y, resp, q=None, q_lat=None, snr=None, use_graphs=True:

@@ -31,10 +31,8 @@ def run_model(g, y, it_limit=None):
 
 def traced(sw, run):
     """run() with the loop's entry points wrapped like tests/golden/make_golden.py::_trace_loop wraps the reference's."""
-    from hdpgpc_amd.GPI_model import GPI_model
-
     tr = {"order": [], "elbo": [], "qall": [], "fpw": [], "em": []}
-    o_elbo, o_qall, o_vltb, o_fpw = sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch, GPI_model.full_pass_weighted
+    o_elbo, o_qall, o_vltb = sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch
     lab = lambda r: torch.argmax(r, dim=1).numpy().astype(np.int16)   # noqa: E731
 
     def w_elbo(resp, respPair, q, q_lat, gpmodels, M, *a, **k):
@@ -49,14 +47,13 @@ def traced(sw, run):
         tr["qall"].append(lab(out[0]))
         return out
 
-    def w_fpw(self, x_, y_, resp, q=None, q_lat=None, snr=None, **k):
-        out = o_fpw(self, x_, y_, resp, q=q, q_lat=q_lat, snr=snr, **k)
+    def w_fpw(resp, out):
+        # GPI_HDP._note_full_pass: one call per full pass, in the order the reference's loop makes them (the passes themselves run
+        # in batches of independent chains, hdpgpc_amd/chain_batch.py)
         tr["order"].append(2)
         mem = torch.nonzero(torch.as_tensor(resp) > 0.99).reshape(-1).numpy()
         tr["fpw"].append((float(len(mem)), float(mem[0]) if len(mem) else -1.0, float(mem[-1]) if len(mem) else -1.0,
-                          float(torch.sum(out[0])) if out[0] is not None else 0.0,
-                          float(torch.sum(out[1])) if out[1] is not None else 0.0))
-        return out
+                          float(torch.sum(out[0])) if out is not None else np.nan, float(torch.sum(out[1])) if out is not None else np.nan))
 
     def w_vltb(*a, **k):
         out = o_vltb(*a, **k)
@@ -64,13 +61,12 @@ def traced(sw, run):
         tr["em"].append((lab(out[0]), out[2].cpu().numpy().copy(), out[3].cpu().numpy().copy(), bool(out[5])))
         return out
 
-    sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch = w_elbo, w_qall, w_vltb
-    GPI_model.full_pass_weighted = w_fpw
+    sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch, sw._note_full_pass = w_elbo, w_qall, w_vltb, w_fpw
     try:
         run()
     finally:
-        GPI_model.full_pass_weighted = o_fpw
         sw.compute_q_elbo, sw.estimate_q_all, sw.variational_local_terms_batch = o_elbo, o_qall, o_vltb
+        del sw._note_full_pass
     return tr
 
 
@@ -134,7 +130,8 @@ def compare_trace(g, sw, tr, q_tol=1e-8, n_em=None):
         worst = max(worst, _rel(tr["elbo"][i][1:3], g["elbo_vals"][i][:2]))
     fp = np.array(tr["fpw"])
     assert np.array_equal(fp[:, :3], g["fpw"][:n_fpw, :3]), "full_pass_weighted: member sets differ"
-    worst = max(worst, _rel(fp[:, 3:], g["fpw"][:n_fpw, 3:]))
+    has = fp[:, 0] > 0                                   # a pass without members hands back its caller's columns: nothing to compare
+    worst = max(worst, _rel(fp[has, 3:], g["fpw"][:n_fpw][has, 3:]))
     for i in range(n_emr):
         worst = max(worst, _rel(tr["em"][i][1], g[f"em{i}_q"]), _rel(tr["em"][i][2], g[f"em{i}_q_lat"]))
     _note(worst)

@@ -178,10 +178,10 @@ def test_producer_full_pass_weighted_reproduces_reference_state(tag, members):
     assert m.indexes == members
     tol = 1e-9      # SURVEY section 7's gate; observed 1e-10 (gpurun_out/parity_observed.json)
     for name in ("f_star", "f_star_sm"):
-        got = torch.stack(getattr(m, name)).cpu().numpy()[:, :, 0]
+        got = torch.stack(list(getattr(m, name))).cpu().numpy()[:, :, 0]
         assert relclose(got, g["st_" + name], tol), name
     for name in ("cov_f_sm", "A", "Gamma", "C", "Sigma"):
-        got = torch.stack(getattr(m, name)).cpu().numpy()
+        got = torch.stack(list(getattr(m, name))).cpu().numpy()
         ref = g["st_" + name]
         assert got.shape == ref.shape, name
         assert relclose(got, ref, tol), name
@@ -214,7 +214,7 @@ def test_producer_step_forms_agree(monkeypatch):
         m.fixed_theta = tuple(float(v) for v in g["st_theta"])
         q, q_lat = m.full_pass_weighted(xs, y[:, :, None], resp, use_graphs=(form != "eager"))
         assert (getattr(m, "graph_replays", 0) > 0) == (form != "eager")
-        states.append({k: torch.stack(getattr(m, k)).cpu().numpy() for k in ("f_star", "f_star_sm", "cov_f", "cov_f_sm", "A", "Gamma", "C", "Sigma")}
+        states.append({k: torch.stack(list(getattr(m, k))).cpu().numpy() for k in ("f_star", "f_star_sm", "cov_f", "cov_f_sm", "A", "Gamma", "C", "Sigma")}
                       | {"q": q.cpu().numpy(), "q_lat": q_lat.cpu().numpy()[members], "n0": np.asarray(float(m.internal_params.n0))})
     for other in states[1:]:
         for k, ref in states[0].items():
@@ -242,10 +242,10 @@ def test_soft_members_are_skipped_like_the_reference():
         q, q_lat = m.full_pass_weighted(xs, y[:, :, None], resp, use_graphs=use_graphs)
         assert m.indexes == members
         for name in ("f_star", "f_star_sm"):
-            got = torch.stack(getattr(m, name)).cpu().numpy()[:, :, 0]
+            got = torch.stack(list(getattr(m, name))).cpu().numpy()[:, :, 0]
             assert relclose(got, g["st_" + name], 1e-9), name
         for name in ("A", "Gamma", "C", "Sigma"):
-            got = torch.stack(getattr(m, name)).cpu().numpy()
+            got = torch.stack(list(getattr(m, name))).cpu().numpy()
             assert relclose(got, g["st_" + name], 1e-9), name
         assert rel_err(q.cpu().numpy(), g["q_shared"]) < 1e-9
 
@@ -330,7 +330,7 @@ def test_replay_offline_trace_from_labels():
         S = len(mod.f_star)
         means = np.stack([(mod.C[min(i, len(mod.C) - 1)] @ mod.f_star[i]).cpu().numpy().reshape(-1) for i in range(S)])
         assert relclose(means, g[f"m{mi}_means"], 1e-9)
-        Sg = torch.stack(mod.Sigma).cpu().numpy()
+        Sg = torch.stack(list(mod.Sigma)).cpu().numpy()
         assert relclose(Sg, g[f"m{mi}_Sigma"], 1e-9)
         assert float(mod.internal_params.n0) == float(g[f"m{mi}_n0"])
         assert rel_err(qlat.cpu().numpy()[members], g[f"m{mi}_q_lat"][members]) < 1e-9
