@@ -169,6 +169,31 @@ def secondary_large_T(dev, ops, synth, N=4096, K=16, T=256, reps=3):
                          "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T)}}
 
 
+def secondary_pairs_t90(dev, ops, synth, N=2048, K=8, T=90, reps=10):
+    """The per-pair path at the REAL data's size (MIT-BIH beats: T = 90, k_pairs<6>), irregular grids, same accounting as the
+    headline (T^3/3 + 3 T^2 algorithmic FLOPs per eval against the fp64 MFMA peak)."""
+    b = synth.synthetic_batch(N, K, T, seed=20260703)
+    d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
+    plan = ops.PairsPlan(T, T, b["theta"], device=dev)
+    xb, mean, Sig, x, y = d(b["xb"]), d(b["mean"]), d(b["Sigma"]), d(b["x"]), d(b["y"])
+    plan.update(xb, mean, Sig)
+    for _ in range(2):
+        plan.loglik(x, y, want_logdet=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        quad, _, info = plan.loglik(x, y, want_logdet=False)
+    e1.record()
+    torch.cuda.synchronize()
+    assert int(info.abs().max()) == 0 and bool(torch.isfinite(quad).all())
+    ms = e0.elapsed_time(e1) / reps
+    tf = N * K * algorithmic_flops_per_eval(T) / (ms * 1e-3) / 1e12
+    return {"workload": f"per-pair path at the records' size: {N} segments x {K} clusters, T={T}, irregular grids (k_pairs<6>)",
+            "value": N * K / (ms * 1e-3), "unit": "evals/s", "kernel_ms": ms,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T)}}
+
+
 def secondary_rank1(dev, ops, b=1024, T=256, reps=5):
     """BASELINE configs[4]'s kernel: L <- chol(alpha L L^T + beta v v^T) by a rank-1 update, batch of b factors, T = 256.
     HBM-bound: 8 T^2 algorithmic bytes per update (the lower triangle in and out)."""
@@ -353,6 +378,7 @@ def main():
             res["roofline"]["frac_ceiling"] = algorithmic_flops_per_eval(t_len) / ex
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_shared_grid(dev, ops)
+            res["secondary_pairs_T90"] = secondary_pairs_t90(dev, ops, synth)
             res["secondary_large_T"] = secondary_large_T(dev, ops, synth)
             # the WHOLE batch of configs[3] on this one GPU: the N = 1 point of the strong-scaling curve `--gpus N > 1` measures
             # (there the headline line itself is configs[3], 32 768 / N rows per rank)
