@@ -915,18 +915,12 @@ class GPI_model:
         return -0.5 * quad - 0.5 * T * LOG2PI
 
     def _pairs_plan(self, Ts, K):
-        """Per-pair plans (device buffer + handle) are kept per (segment length, cluster count, theta): the online loop calls
-        log_sq_error 1 + 2M times per beat on irregular grids; only update() (the per-cluster operators) runs per call."""
+        """Per-pair plans (device buffer + handle) are reused across calls: the online loop calls log_sq_error 1 + 2M times per
+        beat on irregular grids; only update() (the per-cluster operators) runs per call.  A plan is 37 MiB (T = 90, one
+        cluster) to 410 MiB (T = 256, 16 clusters) of device memory and a GPI_HDP holds M x n_outputs models, so the plans live
+        in ONE least-recently-used cache per process, bounded in bytes (ops.plan_cache), not per model."""
         theta = tuple(float(v) for v in self.gp.kernel.params())
-        cache = self.__dict__.setdefault("_plans", {})
-        key = (int(Ts), int(K), theta)
-        plan = cache.get(key)
-        if plan is None:
-            if len(cache) >= 8:
-                cache.pop(next(iter(cache)))
-            plan = ops.PairsPlan(self.x_basis.shape[0], int(Ts), np.repeat(np.asarray(theta)[None], int(K), 0), device=self.device)
-            cache[key] = plan
-        return plan
+        return ops.plan_cache(self.x_basis.shape[0], int(Ts), int(K), theta, self.device)
 
     # ------------------------------------------------------------------ a5
     def log_sq_error(self, x_train, y, mean=None, cov=None, C=None, Sigma=None, i=None, proj=False, first=False):

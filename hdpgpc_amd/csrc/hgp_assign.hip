@@ -21,7 +21,7 @@ __global__ __launch_bounds__(1024) void k_loglik_rows(const double* __restrict__
     double m = q[(size_t)n * K];
     for (int k = 1; k < K; ++k) {
       const double v = q[(size_t)n * K + k];
-      m = (v > m || m != m) ? v : m;      // torch.max: NaN propagates from later entries only through comparisons; keep simple
+      m = (v > m || v != v) ? ((m != m) ? m : v) : m;      // torch.max: a NaN anywhere in the row is the row's maximum
     }
     if (rowmax) rowmax[n] = m;
     bad |= isinf(m) ? 1 : 0;
@@ -35,14 +35,15 @@ __global__ __launch_bounds__(1024) void k_loglik_rows(const double* __restrict__
       m = q[(size_t)n * K];
       for (int k = 1; k < K; ++k) {
         const double v = q[(size_t)n * K + k];
-        m = (v > m || m != m) ? v : m;
+        m = (v > m || v != v) ? ((m != m) ? m : v) : m;
       }
     }
     for (int k = 0; k < K; ++k) out[(size_t)n * K + k] = q[(size_t)n * K + k] - m;
   }
 }
 
-// labels[n] = first arg-max over k of log(fmsg[n,k] * bmsg[n,k]); resp (optional) = its one-hot row.
+// labels[n] = first arg-max over k of log(fmsg[n,k] * bmsg[n,k]); resp (optional) = its one-hot row.  torch.argmax treats NaN
+// as the maximum (first NaN wins): a failed factorisation upstream lands on the NaN column here as it does in the reference.
 __global__ __launch_bounds__(256) void k_assign(const double* __restrict__ fmsg, const double* __restrict__ bmsg, int N, int K,
                                                 int64_t* __restrict__ labels, double* __restrict__ resp) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void k_assign(const double* __restrict__ fmsg,
   double bv = log(fmsg[(size_t)n * K] * bmsg[(size_t)n * K]);
   for (int k = 1; k < K; ++k) {
     const double v = log(fmsg[(size_t)n * K + k] * bmsg[(size_t)n * K + k]);
-    if (v > bv) {
+    if ((v > bv || v != v) && bv == bv) {      // a NaN already held is never replaced; the first NaN replaces any number
       bv = v;
       best = k;
     }

@@ -4,7 +4,7 @@
 // products at T = 90.  Measured (rocprofv3, record 100): every dependent launch costs ~4.5 us whatever it does - a 90^3
 // product adds ~2 us of work on top - so the step's ~40 launches (one per product, plus element-wise glue) WERE its 0.28 ms.
 // Here every dependency level is one launch of k_gemm_list: a device-resident list of heterogeneous items
-//     C = alpha op(A) op(B) + beta D        (any M x N x K <= 128; vectors are N = 1; D may alias nothing or be a vector)
+//     C = alpha op(A) op(B) + beta D        (any M x N x K <= 256; vectors are N = 1; D may alias nothing or be a vector)
 // with all pointers fixed for the life of the chain (the state rows of the step are gathered into one workspace first), and
 // the two Cholesky inversions of the step carry their right-hand sides along (k_wave_inv_rhs: Z = L^-1 and Y = L^-1 op(B) from
 // one factorisation), which removes a product level behind each of them.
@@ -104,8 +104,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave_inv_rhs(InvRhsArgs a) {
   const bool is_rhs = Jq >= NB;
   const int Jc = is_rhs ? Jq - NB : Jq;
   if (16 * Jc >= T) return;
-  if (is_rhs && (!a.rhs || (a.rhs_on && a.rhs_on[m] == 0))) return;
-  if (!is_rhs && !a.Linv) return;
+  const bool skip = (is_rhs && (!a.rhs || (a.rhs_on && a.rhs_on[m] == 0))) || (!is_rhs && !a.Linv);
+  if (skip) {     // an item nobody factors (no Linv wanted, right-hand side switched off) still reports a defined status
+    if (Jq == 0 && !a.Linv && lane == 0 && a.info && (!a.rhs || (a.rhs_on && a.rhs_on[m] == 0))) a.info[m] = 0;
+    return;
+  }
   double* scr = scr_all + wave * DIAG_SCR;
   const double* A = a.A + (size_t)m * T * T;
   d4 U[NB * (NB + 1) / 2];

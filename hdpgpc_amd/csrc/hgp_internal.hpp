@@ -106,6 +106,6 @@ struct PairsArgs {
 #ifdef HGP_STAMPS
 extern unsigned long long* hgp_internal_stamp_dev;
 #endif
-int hgp_internal_pairs_fast(const PairsArgs& a, int NB, bool coop, bool four_wave, hipStream_t st);
+int hgp_internal_pairs_fast(const PairsArgs& a, int NB, bool coop, hipStream_t st);
 // hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device), under a lock
 int hgp_internal_ensure_dynamic_lds(const void* fn, size_t bytes);

@@ -1446,8 +1446,7 @@ static int tp_for(int n) {   // padded size: wave kernels {32,64,96,128}, cooper
   if (n <= HGP_MAX_T_WAVE) return 16 * nb_for(n);
   return n <= 192 ? 192 : 256;
 }
-// Diagnostic switches: HGP_PAIRS_COOP=1 (read when a plan is created) runs the cooperative kernels for T <= 128 too;
-// HGP_PAIRS_COOP4=1 (read per call) selects the 4-wave cooperative kernel instead of the NB/2-wave one.
+// Diagnostic switch: HGP_PAIRS_COOP=1 (read when a plan is created) runs the cooperative kernels for T <= 128 too.
 static int tp_plan(int n) {
   if (n <= HGP_MAX_T_WAVE && env_on("HGP_PAIRS_COOP")) return 64 * ((n + 63) / 64);
   return tp_for(n);
@@ -1699,7 +1698,7 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
                 hgp_internal_stamp_dev,
 #endif
                 p->K, out_quad, out_logdet, out_info, p->d_escr, p->d_eflags, p->nscr, p->escr_stride};
-    rc = hgp_internal_pairs_fast(a, p->NB, p->coop, env_on("HGP_PAIRS_COOP4"), st);
+    rc = hgp_internal_pairs_fast(a, p->NB, p->coop, st);
   }
   if (rc == 0) rc = hgp_internal_pairs_acc(p, x, y, N, Ts, first_noise, sel, out_quad, out_logdet, out_info, st);
   return rc;

@@ -1,5 +1,6 @@
 // a2 + a5, the per-pair kernels of hgp_loglik_pairs_f64 (explicit-operator evaluation of cov_f): k_pairs<NB> (T <= 128, one
-// wavefront per pair), k_pairs_coop<NB> (4 waves per pair) and k_pairs_cooph<NB> (NB/2 waves per pair) for T <= 256.
+// wavefront per pair) and k_pairs_cooph<NB> (NB/2 waves per pair) for T <= 256.  (The 4-wave cooperative kernel of round 1,
+// k_pairs_coop, 1.28x slower, was removed in round 3.)
 // The plan (per-cluster operators) and the C-ABI live in hgp_kernels.hip; the solve-based kernel in hgp_pairs_acc.hip.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -358,371 +359,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 }
 
 // ------------------------------------------------------------ a2 + a5, cooperative: one workgroup per pair
-// For 128 < T <= 256 a pair does not fit one wave (136 tiles at T = 256).  Here the 4 waves of a workgroup share ONE
-// (segment, cluster) pair: the covariance tiles are dealt by block column in snake order (Coop::owner(J)), at most
-// 40 tiles = 320 VGPR per wave), each wave builds the tiles of its own block columns (K** + two MFMA sweeps, no
-// exchange), then the workgroup factors cooperatively (coop_factor: diagonal block by its owner, row panel and
-// trailing update by column owner, two barriers per step) with the single right-hand side d eliminated on the VALU.
-// E_n lives in LDS in COMPACT form: only the 16x16 blocks with an entry above the cut-off get a slot (2 KB each,
-// [slot][k-step][lane] = the MFMA operand order of both sweeps).  With the reference's length-scale (1.2 on a
-// unit-spaced grid) 3 NB - 2 blocks are active (46 at T = 256, 92 KB).  Blocks beyond the CAP slots are not stored:
-// their operands are recomputed (exp) where they are used - slower, but any grid / length-scale stays correct.
+// For 128 < T <= 256 a pair does not fit one wave (136 tiles at T = 256): the NB/2 waves of a workgroup share ONE (segment,
+// cluster) pair (k_pairs_cooph below).  E_n lives in LDS in COMPACT form: only the 16x16 blocks with an entry above the
+// cut-off get a slot (2 KB each, [slot][k-step][lane] = the MFMA operand order of both sweeps).  With the reference's
+// length-scale (1.2 on a unit-spaced grid) 3 NB - 2 blocks are active (46 at T = 256, 92 KB).  Blocks beyond the CAP slots
+// go to a global scratch area of the workgroup - slower, but any grid / length-scale stays correct.
 // Row tiles of B = M' E[:, J] that no active block (Kt, I <= J) of sweep 2 reads are not computed at all.
 template <int NB>
 struct PairsCoop {
   static constexpr int TP = 16 * NB;
-  static constexpr int CAP = (NB >= 12) ? 48 : (NB == 8 ? 24 : 16);
+  static constexpr int CAP = (NB >= 12) ? 48 : (NB >= 8 ? 24 : 16);   // >= 2 NB: the factorisation reuses the E slots (row buffer, W)
   static constexpr size_t LDS_BYTES =
       sizeof(double) * ((size_t)CAP * 256 + NB * 256 /*rowbuf*/ + 256 /*Wbuf*/ + TP /*dvec*/ + 3 * TP + DIAG_SCR + 16) +
       sizeof(int) * (8 + 16 + 16 + 16 + 20 + NB * NB) + sizeof(double) * 4 * NB;
 };
-
-template <int NB>
-__global__ __launch_bounds__(64 * WAVES) void k_pairs_coop(PairsArgs a) {
-  using C = Coop<NB>;
-  using PC = PairsCoop<NB>;
-  constexpr int TP = 16 * NB, CAP = PC::CAP, NQ = C::NQ;
-  constexpr int CH = (NB == 16) ? 2 : 4;   // row tiles of B[:, J] per pass (register budget: 40 resident tiles at NB = 16)
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Ec = smem;                    // [CAP][4][64]
-  double* rowbuf = Ec + CAP * 256;      // [NB][4][64]
-  double* Wbuf = rowbuf + NB * 256;
-  double* dvec = Wbuf + 256;            // d, then z = L^{-1} d
-  double* xs = dvec + TP;
-  double* ys = xs + TP;
-  double* xbs = ys + TP;
-  double* scr = xbs + TP;
-  double* red = scr + DIAG_SCR;         // 16 doubles
-  int* redi = reinterpret_cast<int*>(red + 16);   // 8
-  int* amask = redi + 8;                // bit Kt of amask[J]: block (Kt, J) of E active
-  int* kmask = amask + 16;              // bit I of kmask[J]: tile (I, J) of K** above the cut-off (I <= J)
-  int* pneed = kmask + 16;              // OR of amask[0..J]: row tiles of B[:, J] that sweep 2 reads
-  int* base = pneed + 16;               // first slot of column J (prefix sum of popcounts), base[NB] = total
-  int* slotblk = base + 20;             // slot -> (Kt << 8) | J
-  double* rng = reinterpret_cast<double*>(slotblk + NB * NB);   // [2 NB][lo, hi] of the real points of each 16-block
-  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int T = a.T, Ts = a.Ts;
-  const int Kg = a.kend - a.kbeg;
-
-  // block -> (segment, cluster).  Without `sel` the Kg clusters of the group are spread over the 8 XCDs (block b runs
-  // on XCD b % 8) so that each XCD's L2 keeps the operators of Kg / 8 clusters only.
-  int n, kc;
-  if (a.sel) {
-    n = blockIdx.x;
-    kc = a.sel[n];
-    bool mine = false;
-    for (int kk = a.kbeg; kk < a.kend; ++kk) mine = mine || (a.perm[kk] == kc);
-    if (!mine) return;
-  } else {
-    const int b = blockIdx.x;
-    int kk;
-    if ((Kg & 7) == 0) {
-      const int cpx = Kg >> 3, s = b >> 3;
-      kk = (b & 7) + 8 * (s % cpx);
-      n = s / cpx;
-    } else {
-      kk = b % Kg;
-      n = b / Kg;
-    }
-    kc = a.perm[a.kbeg + kk];
-  }
-  if (a.scal[8 * kc + 7] != 0.0) return;   // ill-conditioned K~: scored by the solve-based kernel (hgp_pairs_acc.hip)
-
-  HGP_STAMP_DECL
-  HGP_T0();
-  for (int i = tid; i < TP; i += 64 * WAVES) {   // sentinel padding as in k_pairs
-    xs[i] = (i < Ts) ? a.x[(size_t)n * Ts + i] / a.ell : 1e150 * (double)(1 + i);
-    ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
-    xbs[i] = (i < T) ? a.xb[i] / a.ell : -1e150 * (double)(1 + i);
-  }
-  if (tid < 16) {
-    amask[tid] = 0;
-    kmask[tid] = 0;
-  }
-  __syncthreads();
-  // Which 16x16 blocks of E (and tiles of K**) can hold an entry above the cut-off?  Decided from the data: the
-  // range [min, max] of the REAL points of every 16-block (padding excluded), then block (Kt, J) is active iff the
-  // two ranges are closer than the cut-off radius.  Exact for sorted grids, a superset otherwise (never drops a block).
-  for (int b16 = wave; b16 < 2 * NB; b16 += WAVES) {
-    const int B = (b16 < NB) ? b16 : b16 - NB;
-    const int i = 16 * B + c;
-    const bool real = (b16 < NB) ? (i < T) : (i < Ts);
-    const double v = (b16 < NB) ? xbs[i] : xs[i];
-    double lo = real ? v : __builtin_inf(), hi = real ? v : -__builtin_inf();
-#pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) {
-      lo = fmin(lo, __shfl_xor(lo, o, 64));
-      hi = fmax(hi, __shfl_xor(hi, o, 64));
-    }
-    if (lane == 0) {
-      rng[2 * b16] = lo;
-      rng[2 * b16 + 1] = hi;
-    }
-  }
-  __syncthreads();
-  bool actE = false;
-  int myKt = 0, myJb = 0;
-  if (tid < NB * NB) {
-    myKt = tid / NB;
-    myJb = tid % NB;
-    const double xlo = rng[2 * (NB + myJb)], xhi = rng[2 * (NB + myJb) + 1];
-    const double gE = fmax(0.0, fmax(rng[2 * myKt] - xhi, xlo - rng[2 * myKt + 1]));
-    actE = 0.5 * (gE * gE) < PAIRS_CUT;
-    if (actE) atomicOr(&amask[myJb], 1 << myKt);
-    if (myKt <= myJb) {
-      const double gK = fmax(0.0, fmax(rng[2 * (NB + myKt)] - xhi, xlo - rng[2 * (NB + myKt) + 1]));
-      if (0.5 * (gK * gK) < PAIRS_CUT) atomicOr(&kmask[myJb], 1 << myKt);
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int s = 0, o = 0;
-    for (int J = 0; J < NB; ++J) {
-      base[J] = s;
-      s += __popc(amask[J]);
-      o |= amask[J];
-      pneed[J] = o;
-    }
-    base[NB] = s;
-  }
-  __syncthreads();
-  if (actE) slotblk[base[myJb] + __popc(amask[myJb] & ((1 << myKt) - 1))] = (myKt << 8) | myJb;
-  const int nslot = __builtin_amdgcn_readfirstlane(base[NB]);
-  // Dense grids: the blocks beyond the LDS slots go to a global scratch area of this workgroup.  Areas are handed out
-  // with a compare-and-swap on a flag array that has more entries than workgroups can be resident at once.
-  double* Eov = nullptr;
-  int my_area = -1;
-  if (nslot > CAP) {
-    if (tid == 0) {
-      int sidx = blockIdx.x % a.nscr;
-      while (atomicCAS(&a.eflags[sidx], 0, 1) != 0) sidx = (sidx + 1 == a.nscr) ? 0 : sidx + 1;
-      redi[7] = sidx;
-    }
-    __syncthreads();
-    my_area = redi[7];
-    Eov = a.escr + (size_t)my_area * a.escr_stride;
-  }
-  __syncthreads();
-  for (int slot = wave; slot < nslot; slot += WAVES) {
-    const int kj = __builtin_amdgcn_readfirstlane(slotblk[slot]);
-    const int Kt = kj >> 8, Jb = kj & 255;
-    double* dst = (slot < CAP) ? Ec + slot * 256 : Eov + (size_t)(slot - CAP) * 256;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const double u = xbs[16 * Kt + 4 * s + g] - xs[16 * Jb + c];
-      dst[s * 64 + lane] = exp(-0.5 * (u * u));
-    }
-  }
-  __syncthreads();
-  // E[16 Kt + 4 s + g][16 Jb + c] of the block in `slot`: the B operand of sweep 1 (k-step s) and the A operand of sweep 2
-  // (the overflow read is a volatile global load on purpose: with two plain loads the compiler merges the branches
-  //  into ONE flat_load through a selected generic pointer, which costs the LDS path its ds_read and its wait counter)
-  auto e_op = [&](int slot, int s) -> double {
-    if (slot < CAP) return Ec[slot * 256 + s * 64 + lane];
-    return *reinterpret_cast<const volatile double*>(Eov + (size_t)(slot - CAP) * 256 + s * 64 + lane);
-  };
-  auto release_area = [&]() {
-    if (my_area >= 0) {
-      __syncthreads();
-      if (tid == 0) {
-        __threadfence();
-        atomicExch(&a.eflags[my_area], 0);
-      }
-    }
-  };
-
-  HGP_ACC(0);
-  const double* sc = a.scal + 8 * kc;
-  const double cc = sc[0], noise = sc[2];
-  const bool iso = sc[3] != 0.0;
-  const size_t oidx = a.sel ? (size_t)n : (size_t)n * a.K + kc;
-  const double fn = a.first_noise ? a.first_noise[oidx] : 0.0;
-
-  // d = y - E^T a'  (block columns dealt to the waves)
-  const double* apk = a.ap + (size_t)kc * TP;
-  double dsq = 0.0;
-  for (int Jb = wave; Jb < NB; Jb += WAVES) {
-    int m = __builtin_amdgcn_readfirstlane(amask[Jb]);
-    int slot = __builtin_amdgcn_readfirstlane(base[Jb]);
-    double p = 0.0;
-    while (m) {
-      const int Kt = __builtin_ctz(m);
-      m &= m - 1;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) p = fma(e_op(slot, s), apk[16 * Kt + 4 * s + g], p);
-      ++slot;
-    }
-    p = xrow_sum(p);
-    if (g == 0) {
-      const int j = 16 * Jb + c;
-      const double d = ys[j] - p;
-      dvec[j] = d;
-      dsq = fma(d, d, dsq);
-    }
-  }
-  HGP_ACC(1);
-  if (iso) {   // GPI.py:497-498: cov_f = mean(diag Sigma) I
-    dsq = wave_sum(dsq);
-    if (lane == 0) red[wave] = dsq;
-    __syncthreads();
-    if (tid == 0) {
-      const double v = sc[4] + fn;
-      const double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
-      a.out_quad[oidx] = (red[0] + red[1] + red[2] + red[3]) / v2;
-      if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
-      if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
-    }
-    release_area();
-    return;
-  }
-
-  int msk[NB], bas[NB];   // uniform copies for the statically indexed uses of sweep 2
-#pragma unroll
-  for (int I = 0; I < NB; ++I) {
-    msk[I] = __builtin_amdgcn_readfirstlane(amask[I]);
-    bas[I] = __builtin_amdgcn_readfirstlane(base[I]);
-  }
-  const double* Mk = a.Mp + (size_t)kc * TP * TP;   // plain row-major here (no tile-pair interleave)
-  d4 U[C::NT];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int J = C::col(q, wave);
-    const int mJ = __builtin_amdgcn_readfirstlane(amask[J]), bJ = __builtin_amdgcn_readfirstlane(base[J]);
-    const int kmJ = __builtin_amdgcn_readfirstlane(kmask[J]), need = __builtin_amdgcn_readfirstlane(pneed[J]);
-    // K** = c exp(-0.5 (x_i - x_j)^2) + noise I on my column (the one-argument kernel call, GPI.py:476)
-#pragma unroll
-    for (int I = 0; I < 4 * q + 4; ++I) {
-      const int ln = launder(lane);
-      d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
-      if (I <= J) {
-        if (kmJ & (1 << I)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
-            kt[r] = cc * exp(-0.5 * (u * u));
-          }
-        }
-        if (I == J) {   // exact diagonal; identity on the padding
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if ((ln >> 4) + 4 * r == (ln & 15)) kt[r] = (16 * I + (ln & 15) < Ts) ? cc + noise : 1.0;
-        }
-      }
-      U[C::loc(I, q)] = kt;
-    }
-    HGP_ACC(2);
-#pragma nounroll
-    for (int h = 0; h < NB / CH; ++h) {
-      const int nb4 = (need >> (CH * h)) & ((1 << CH) - 1);
-      if (!nb4) continue;
-      // sweep 1: BJ[i] = M'[rows of tile 4h + i, :] E[:, J] over the active blocks of column J.  M' is symmetric:
-      // the A operand of output row tile i, k-step s of block Kt is M'[16 Kt + 4 s + g][16 (4h + i) + c] (coalesced).
-      d4 BJ[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) BJ[i] = (d4){0.0, 0.0, 0.0, 0.0};
-      const double* Mh = Mk + (size_t)g * TP + 16 * CH * h + c;
-      double ra[2][4][CH], re[2][4];
-#define HGP_CFILL(buf, Kt_, slot_)                                                                  \
-  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
-    const double* row_ = Mh + (size_t)(16 * (Kt_) + 4 * s_) * TP;                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) ra[buf][s_][i_] = row_[16 * i_];               \
-    re[buf][s_] = e_op((slot_), s_);                                                                 \
-  }
-#define HGP_CMMA(buf)                                                                               \
-  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_)                                               \
-      if (nb4 & (1 << i_)) BJ[i_] = mfma(ra[buf][s_][i_], re[buf][s_], BJ[i_]);                     \
-  }
-      int m = mJ, slot = bJ;
-      int kA = -1, kB = -1;
-      if (m) {
-        kA = __builtin_ctz(m);
-        m &= m - 1;
-        HGP_CFILL(0, kA, slot)
-        ++slot;
-      }
-#pragma nounroll
-      while (kA >= 0) {
-        kB = -1;
-        if (m) {
-          kB = __builtin_ctz(m);
-          m &= m - 1;
-          HGP_CFILL(1, kB, slot)
-          ++slot;
-        }
-        HGP_CMMA(0)
-        if (kB < 0) break;
-        kA = -1;
-        if (m) {
-          kA = __builtin_ctz(m);
-          m &= m - 1;
-          HGP_CFILL(0, kA, slot)
-          ++slot;
-        }
-        HGP_CMMA(1)
-      }
-      HGP_ACC(3);
-      // sweep 2: U[I][J] += E[Kt, I]^T BJ[i] over the active blocks (Kt = 4h + i, I <= J) of E.  Per tile the operands
-      // of all its active blocks in this chunk are requested first, then multiplied: one LDS latency per tile.
-#pragma unroll
-      for (int I = 0; I < 4 * q + 4; ++I) {
-        const int m4 = (msk[I] >> (CH * h)) & nb4;
-        if (I <= J && m4) {
-          const int below = __popc(msk[I] & ((1 << (CH * h)) - 1));
-          double af[CH][4];
-#pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            if (m4 & (1 << i)) {
-              const int slot2 = bas[I] + below + __popc(m4 & ((1 << i) - 1));
-#pragma unroll
-              for (int s = 0; s < 4; ++s) af[i][s] = e_op(slot2, s);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            if (m4 & (1 << i)) {
-#pragma unroll
-              for (int s = 0; s < 4; ++s) U[C::loc(I, q)] = mfma(af[i][s], BJ[i][s], U[C::loc(I, q)]);
-            }
-          }
-        }
-      }
-      HGP_ACC(4);
-    }
-  }
-#undef HGP_CFILL
-#undef HGP_CMMA
-
-  // regularisation of the reference: +1e-6 I (GPI.py:501), + first, + 1e-8 mean|diag| I (GPI_model.py:83-87)
-  {
-    const double sh = 1e-6 + fn;
-    const double dm = coop_diag_abs_mean<NB>(U, Ts, wave, lane, sh, red);   // (also orders the dvec writes: barrier)
-    coop_add_diag<NB>(U, sh + 1e-8 * fmax(dm, F64_EPS), Ts, wave, lane);
-  }
-  PivotAcc pa;
-  pa.init();
-  HGP_ACC(5);
-  double zq = coop_factor<NB, 2>(U, rowbuf, nullptr, Wbuf, scr, wave, lane, pa, nullptr, 0, Ts, dvec);
-  int info;
-  const double ld = coop_logdet_info(pa, wave, lane, red, redi, info);
-  zq = wave_sum(zq);
-  if (lane == 0) red[8 + wave] = zq;
-  __syncthreads();
-  if (tid == 0) {
-    a.out_quad[oidx] = red[8] + red[9] + red[10] + red[11];
-    if (a.out_logdet) a.out_logdet[oidx] = ld;
-    if (a.out_info) a.out_info[oidx] = info;
-  }
-  release_area();
-  HGP_ACC(6);
-#ifdef HGP_STAMPS
-  if (tid == 64 * (WAVES - 1) && a.stamps) {   // the view of the last wave
-    for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
-    for (int i = 0; i < 5; ++i) atomicAdd(&a.stamps[8 + i], pa.cf[i]);
-  }
-#endif
-}
 
 // The same pipeline with NB/2 waves per pair (CoopH<NB>, tile_f64.hpp: 8 waves and 17 tiles per wave at NB = 16 instead
 // of 4 waves and 34-40 tiles): more than one wave per SIMD, so the latencies and barrier waits of one wave sit under the
@@ -1056,7 +706,13 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
   PivotAcc pa;
   pa.init();
   HGP_ACC(5);
+#ifdef HGP_COOPH_BARRIERS   // the barrier-synchronised factorisation of rounds 1-2 (A/B builds only)
   double zq = cooph_factor<NB>(U, rowbuf, Wbuf, scr, wave, lane, pa, Ts, dvec);
+#else
+  // dataflow-synchronised (tile_f64.hpp, cooph_factor_df): the E slots are dead now - second row buffer and the W of every step
+  static_assert(CAP >= 3 * NB, "E slots too small for the factorisation's buffers");
+  double zq = cooph_factor_df<NB>(U, rowbuf, Ec, Ec + NB * 256, Ec + 2 * NB * 256, scr, slotblk, wave, lane, pa, Ts, dvec);
+#endif
   int info;
   const double ld = cooph_logdet_info<NB>(pa, wave, lane, red, redi, info);
   zq = wave_sum(zq);
@@ -1089,15 +745,6 @@ int launch_pairs_cooph(const PairsArgs& a, hipStream_t st) {
 }
 
 template <int NB>
-int launch_pairs_coop(const PairsArgs& a, hipStream_t st) {
-  const size_t lds = PairsCoop<NB>::LDS_BYTES;
-  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs_coop<NB>), lds)) return rc_;
-  const int blocks = a.sel ? a.N : a.N * (a.kend - a.kbeg);
-  hipLaunchKernelGGL(k_pairs_coop<NB>, dim3(blocks), dim3(64 * WAVES), lds, st, a);
-  return launch_status();
-}
-
-template <int NB>
 int launch_pairs(const PairsArgs& a, hipStream_t st) {
   size_t lds = pairs_lds_bytes<NB>();
   if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs<NB>), lds)) return rc_;
@@ -1108,13 +755,13 @@ int launch_pairs(const PairsArgs& a, hipStream_t st) {
 }  // namespace
 
 // dispatch by padded size / kernel family (see hgp_loglik_pairs_f64)
-int hgp_internal_pairs_fast(const PairsArgs& a, int NB, bool coop, bool four_wave, hipStream_t st) {
-  if (coop) {   // NB/2 waves per pair (CoopH); four_wave (HGP_PAIRS_COOP4=1) selects the 4-wave kernels (Coop) for comparison
+int hgp_internal_pairs_fast(const PairsArgs& a, int NB, bool coop, hipStream_t st) {
+  if (coop) {   // NB/2 waves per pair (CoopH)
     switch (NB) {
-      case 4: return launch_pairs_coop<4>(a, st);
-      case 8: return four_wave ? launch_pairs_coop<8>(a, st) : launch_pairs_cooph<8>(a, st);
-      case 12: return four_wave ? launch_pairs_coop<12>(a, st) : launch_pairs_cooph<12>(a, st);
-      default: return four_wave ? launch_pairs_coop<16>(a, st) : launch_pairs_cooph<16>(a, st);
+      case 4: return launch_pairs_cooph<4>(a, st);
+      case 8: return launch_pairs_cooph<8>(a, st);
+      case 12: return launch_pairs_cooph<12>(a, st);
+      default: return launch_pairs_cooph<16>(a, st);
     }
   }
   switch (NB) {

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 // Diagnostic build only (make stamps): per-phase cycle sums with s_memtime; no stamp executes in the product build.
 #ifdef HGP_STAMPS
 #define HGP_STAMP_DECL unsigned long long hgp_t_, hgp_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1059,6 +1061,228 @@ __device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* r
   return zq;
 }
 #undef HGP_CF
+
+// ---------------------------------------------------------------------------------------------
+// cooph_factor with DATAFLOW synchronisation instead of two workgroup barriers per block step.
+//
+// What a wave really waits for in step K is (i) W_K (and z_K) from the owner of the diagonal block, (ii) the row tiles
+// (K, I) of exactly those block columns I it still updates, from their owners.  With barriers every wave also waits for the
+// slowest wave's whole phase, and the 16 serial diag16 calls (4.2 k cycles each, one wave busy, seven idle) cannot overlap
+// anybody's trailing update: the stamps show 74 k of the 154 k cycles of the factorisation spent at barriers.
+// Here every produced item has a monotone counter in LDS:
+//     wdone        number of diagonal blocks whose W (own buffer per K) and z_K are published,
+//     rowpub[J]    number of row tiles (K, J), K = 0, 1, .. published by the owner of block column J  (tile K sits in the row
+//                  buffer K % 3: three buffers, so a writer of row K must know that everybody has finished row K - 3:)
+//     tdone[w]     number of block steps whose trailing update wave w has completed,
+// producers store with release, consumers spin (s_sleep) with acquire.  The owner of diagonal block K + 1 factors it as soon
+// as it has updated that one tile in step K - before the rest of its own trailing update - so W_{K+1} is usually there when
+// the other waves finish step K: the diag16 chain runs under the trailing updates of the other waves (two waves share a SIMD:
+// the VALU-only diag16 of one leaves the matrix pipe to the other).  Same arithmetic, same order per tile: bit-identical.
+// A spin that exceeds SPIN_LIMIT sets `err` and falls through (results are then garbage and info reports it) - a bug here
+// must fail a test, not hang the GPU.
+// ---------------------------------------------------------------------------------------------
+constexpr int COOPH_SPIN_LIMIT = 1 << 22;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, B>), ..., f(integral_constant<int, E - 1>)
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+__device__ __forceinline__ void df_publish(int* p, int v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef HGP_RACE_STRESS
+  {
+    const unsigned h = ((threadIdx.x >> 6) + 1u) * 2654435761u ^ (unsigned)(__builtin_readcyclecounter() >> 7);
+    const unsigned n = __builtin_amdgcn_readfirstlane((h >> 5) & 7u);
+    for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
+}
+__device__ __forceinline__ void df_wait_ge(int* p, int v, int* err, bool hot = false) {
+  int it = 0;
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+    if (!hot) __builtin_amdgcn_s_sleep(1);
+    if (++it > COOPH_SPIN_LIMIT) {
+      *err = 1;
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int NW>
+__device__ __forceinline__ void df_wait_all_ge(int* tdone, int v, int lane, int* err) {
+  int it = 0;
+  while (!__all(__hip_atomic_load(&tdone[lane & (NW - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= v)) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++it > COOPH_SPIN_LIMIT) {
+      *err = 1;
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// row0 / row1 / row2: three row buffers [NB][4][64]; Wall: [NB][4][64]; flags: 16 + NB ints (zeroed here).
+// Two refinements on the critical path (the chain diag16(K) -> W_K -> tile (K, K+1) -> tile (K+1, K+1) -> diag16(K+1)):
+//  * the owner of block K + 1 solves ONLY that panel tile first, updates its diagonal tile straight from the accumulator (no LDS
+//    round trip), factors it and publishes W_{K+1} - its other panel tile and the rest of its trailing update come afterwards;
+//  * the wave that will factor the next diagonal block polls for W_K without sleeping.
+// (Measured and dropped: the SIMD-mate of the wave on the pivot chain holding its MFMAs back while the chain runs - f64 MFMA and
+//  VALU instructions of two waves on one SIMD do not overlap - is SLOWER, 3.93 vs 3.69 ms per 8 192 pairs at T = 256: the polls
+//  cost every tile update an LDS round trip; s_setprio(3) on the chain wave is worth 0.7 %.)
+template <int NB>
+__device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double* row0, double* row1, double* row2, double* Wall,
+                                                  double* scr, int* flags, int wave, int lane_in, PivotAcc& pa, int n, double* dvec) {
+  using C = CoopH<NB>;
+  int* wdone = flags;
+  int* tdone = flags + 1;        // [8]
+  int* err = flags + 9;
+  int* rowpub = flags + 16;      // [NB]
+  if (threadIdx.x < 16 + NB) flags[threadIdx.x] = 0;
+  __syncthreads();
+  double zq = 0.0;
+  const int JA = wave, JB = NB - 1 - wave;   // my block columns
+#ifdef HGP_STAMPS
+  unsigned long long cf_t = __builtin_readcyclecounter();
+#define HGP_DF(i) do { unsigned long long n_ = __builtin_readcyclecounter(); pa.cf[i] += n_ - cf_t; cf_t = n_; } while (0)
+#else
+#define HGP_DF(i)
+#endif
+
+  auto do_diag = [&](auto Kc) {
+    constexpr int K = decltype(Kc)::value;
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+    HGP_DF(4);
+    __builtin_amdgcn_s_setprio(3);
+    const d4 Wd = diag16(U[C::diag_slot(K)], scr, lane, pa, 16 * K, nullptr, 0, n - 16 * K);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Wall[(K * 4 + s) * 64 + lane] = Wd[s];
+    double p = 0.0;   // z_K = W d_K
+#pragma unroll
+    for (int s = 0; s < 4; ++s) p = fma(Wd[s], dvec[16 * K + 4 * s + g], p);
+    p = xrow_sum(p);
+    __builtin_amdgcn_wave_barrier();
+    if (g == 0) {
+      dvec[16 * K + c] = p;
+      zq = fma(p, p, zq);
+    }
+    df_publish(wdone, K + 1, lane_in);
+    __builtin_amdgcn_s_setprio(0);
+    HGP_DF(0);
+  };
+  if (wave == C::owner(0)) do_diag(std::integral_constant<int, 0>{});
+  static_for<0, NB>([&](auto Kc) {
+    constexpr int K = decltype(Kc)::value;
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+    HGP_DF(4);
+    df_wait_ge(wdone, K + 1, err, (K + 1 < NB) && wave == C::owner(K + 1 < NB ? K + 1 : 0));
+    HGP_DF(1);
+    d4 W;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) W[s] = Wall[(K * 4 + s) * 64 + lane];
+    double zr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zr[r] = dvec[16 * K + g + 4 * r];
+    double* rb = (K % 3 == 0) ? row0 : (K % 3 == 1 ? row1 : row2);      // three row buffers: the writer of row K needs row K - 3 dead
+    const bool haveA = (K < C::NW) && (JA > K), haveB = JB > K;
+    if constexpr (K >= 3) {
+      if (haveA || haveB) {
+        if constexpr ((C::NW & (C::NW - 1)) == 0) df_wait_all_ge<C::NW>(tdone, K - 2, lane_in, err);
+        else {
+          for (int w = 0; w < C::NW; ++w) df_wait_ge(&tdone[w], K - 2, err);
+        }
+      }
+    }
+    HGP_DF(3);
+    // panel tile (K, J) of my column h (0: JA, 1: JB) + the right-hand side; returns the tile
+    auto panel_col = [&](auto hc) -> d4 {
+      constexpr int h = decltype(hc)::value;
+      constexpr int sl = (h == 0) ? C::slotA(K < C::NW ? K : 0) : C::slotB(K);
+      const int J = (h == 0) ? JA : JB;
+      const d4 t = U[sl];
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma(W[s], t[s], acc);
+      U[sl] = acc;
+      lds_tile_store(rb, J, lane, acc);
+      double tq = 0.0;                          // d_J -= U_KJ^T z_K
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tq = fma(acc[r], zr[r], tq);
+      tq = xrow_sum(tq);
+      if (g == 0) dvec[16 * J + c] -= tq;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane_in == 0) __hip_atomic_store(&rowpub[J], K + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return acc;
+    };
+    // is this wave the owner of the NEXT diagonal block?  then that block's column goes first (critical path)
+    constexpr int HC = (K + 1 < C::NW) ? 0 : 1;                 // column (A / B) of block K + 1 in its owner's registers
+    bool crit = false;
+    if constexpr (K + 1 < NB) crit = (wave == C::owner(K + 1));
+#ifdef HGP_DF_NOCRIT
+    crit = false;
+#endif
+    if constexpr (K + 1 < NB) {
+      if (crit) {
+        const d4 acc = panel_col(std::integral_constant<int, HC>{});
+        HGP_DF(2);
+        constexpr int sd = C::diag_slot(K + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) U[sd] = mfma_sub(acc[s], acc[s], U[sd]);      // tile (K+1, K+1) -= U_K,K+1^T U_K,K+1
+        do_diag(std::integral_constant<int, K + 1>{});
+      }
+    }
+    if (!(crit && HC == 0) && haveA) {
+      if constexpr (K < C::NW) {
+        panel_col(std::integral_constant<int, 0>{});
+      }
+    }
+    if (!(crit && HC == 1) && haveB) {
+      panel_col(std::integral_constant<int, 1>{});
+    }
+    HGP_DF(2);
+    // trailing: A_IJ -= U_KI^T U_KJ for my columns J >= I > K
+    static_for<K + 1, NB>([&](auto Ic) {
+      constexpr int I = decltype(Ic)::value;
+      bool needA = (I < C::NW) && (K < C::NW) && (JA >= I), needB = JB >= I;
+      if constexpr (I == K + 1) {               // the owner of block K + 1 has already updated its diagonal tile
+        if (crit && HC == 0) needA = false;
+        if (crit && HC == 1) needB = false;
+      }
+      if (needA || needB) {
+        HGP_DF(4);
+        df_wait_ge(&rowpub[I], K + 1, err);
+        HGP_DF(3);
+        const d4 ucur = lds_tile_load(rb, I, lane);
+        if constexpr (I < C::NW && K < C::NW) {
+          if (needA) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) U[C::slotA(I)] = mfma_sub(ucur[s], U[C::slotA(K)][s], U[C::slotA(I)]);
+          }
+        }
+        if (needB) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) U[C::slotB(I)] = mfma_sub(ucur[s], U[C::slotB(K)][s], U[C::slotB(I)]);
+        }
+      }
+#ifdef HGP_DF_NOCRIT
+      if constexpr (I == K + 1) {
+        if (wave == C::owner(I)) do_diag(std::integral_constant<int, I>{});
+      }
+#endif
+    });
+    df_publish(&tdone[wave], K + 1, lane_in);
+  });
+  __syncthreads();
+  if (*err) pa.info = 1;
+  return zq;
+}
+#undef HGP_DF
 
 template <int NB>
 __device__ __forceinline__ double cooph_logdet_info(const PivotAcc& pa, int wave, int lane, double* red, int* redi, int& info) {

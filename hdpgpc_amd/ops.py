@@ -258,6 +258,29 @@ class PairsPlan:
             pass
 
 
+_PLANS = {}                        # (device, T, Ts, K, theta) -> PairsPlan, in least-recently-used order
+PLAN_CACHE_BYTES = 1 << 30         # device bytes the cached plans may hold together (the newest plan always stays)
+
+
+def plan_cache(T, Ts, K, theta, device):
+    """A PairsPlan for K clusters that share one theta, from a process-wide LRU cache bounded by PLAN_CACHE_BYTES.  Plans are
+    stateless between calls as far as callers are concerned: every use starts with update()."""
+    key = (str(device), int(T), int(Ts), int(K), tuple(theta))
+    plan = _PLANS.pop(key, None)
+    if plan is None:
+        plan = PairsPlan(T, Ts, np.repeat(np.asarray(theta, dtype=np.float64)[None], int(K), 0), device=device)
+    _PLANS[key] = plan                                     # most recently used = last
+    total = sum(p._buf.numel() for p in _PLANS.values())
+    for k in list(_PLANS):
+        if total <= PLAN_CACHE_BYTES or k == key:
+            break
+        old = _PLANS.pop(k)
+        total -= old._buf.numel()
+        old.close()
+        old._buf = None
+    return plan
+
+
 def gemm_batched(A, B, transA=False, transB=False, alpha=1.0, add=None, beta=1.0, out=None):
     """C[b] = alpha op(A[b]) op(B[b]) (+ beta add[b]) on v_mfma_f64_16x16x4_f64; A [b,m,k] (or [m,k]), B [b,k,n] (or [k,n]).
     add: optional [m,n] (shared by the batch) or [b,m,n] addend fused into the epilogue; out: optional preallocated

@@ -208,3 +208,50 @@ def test_hmm_messages_edge_sizes(N, K):
     assert np.allclose(b.cpu().numpy(), br, rtol=1e-10, atol=1e-300, equal_nan=True)
     z = ctypes.c_void_p(16)
     assert _ffi.lib.hgp_hmm_messages_f64(z, z, z, 3, 65, z, z, z, None, None) == -2
+
+
+def test_pair_plans_are_cached_in_a_bounded_lru():
+    """plans used to be cached per model (up to 8 each, 37-410 MiB apiece).  Scoring many (segment length, cluster
+    count) shapes through several models must keep the device memory of the cached plans under ops.PLAN_CACHE_BYTES."""
+    import torch
+    from hdpgpc_amd import ops
+    from hdpgpc_amd.GPI import RBFWhiteKernel
+    from hdpgpc_amd.GPI_model import GPI_model
+    T = 48
+    models = []
+    for i in range(3):
+        m = GPI_model(RBFWhiteKernel(300.0, 1.2 + 0.1 * i, 0.5), np.arange(float(T))[:, None], annealing=True, bayesian=True, free_deg_MNIV=5)
+        cond = m.GPR_dynamic(2.0, 1.0)
+        m.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
+        models.append(m)
+    rng = np.random.default_rng(0)
+    old = ops.PLAN_CACHE_BYTES
+    ops.PLAN_CACHE_BYTES = 64 << 20
+    try:
+        peak = 0
+        for Ts in range(20, 48, 2):
+            x = np.sort(rng.uniform(0, T - 1, Ts))[:, None]
+            y = rng.normal(size=(Ts, 1))
+            for m in models:
+                assert np.isfinite(float(m.log_sq_error(x, y, i=-1)))
+            held = sum(p._buf.numel() for p in ops._PLANS.values())
+            peak = max(peak, held)
+            assert held <= max(ops.PLAN_CACHE_BYTES, max(p._buf.numel() for p in ops._PLANS.values()))
+        assert len(ops._PLANS) < 3 * 14 and peak > 0
+    finally:
+        ops.PLAN_CACHE_BYTES = old
+
+
+def test_assignment_tail_treats_nan_like_torch():
+    """torch.max / torch.argmax of the reference's LogLik / _safe_exp treat NaN as the maximum: a NaN score in a
+    non-first column must poison the row maximum and win the arg-max, as it does there."""
+    import torch
+    from hdpgpc_amd import ops
+    q = torch.tensor([[-3.0, float("nan"), -1.0], [-2.0, -5.0, -4.0], [float("nan"), 1.0, 2.0]], dtype=torch.float64, device="cuda")
+    out, rowmax = ops.loglik_rows(q.contiguous())
+    ref = torch.max(q.cpu(), dim=1)[0]
+    assert torch.equal(torch.isnan(rowmax.cpu()), torch.isnan(ref)) and float(rowmax[1]) == -2.0
+    f = torch.tensor([[0.2, float("nan"), 0.5], [0.1, 0.7, 0.2], [0.3, 0.3, float("nan")]], dtype=torch.float64, device="cuda")
+    b = torch.ones_like(f)
+    labels = ops.assign(f.contiguous(), b.contiguous()).cpu()
+    assert torch.equal(labels, torch.argmax(torch.log(f.cpu() * b.cpu()), dim=1))

@@ -2,7 +2,7 @@
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["HGP_LIB"] = os.path.join(ROOT, "hdpgpc_amd", "lib", "libhdpgpc_hip_stamps.so")
+os.environ.setdefault("HGP_LIB", os.path.join(ROOT, "hdpgpc_amd", "lib", "libhdpgpc_hip_stamps.so"))
 import hdpgpc_amd._ffi as ffi
 import numpy as np, torch
 from hdpgpc_amd import ops
@@ -41,4 +41,4 @@ for (N, K, T) in [(256, 16, 256), (256, 16, 192)]:
     for nme, val in zip(names, v):
         print(f"   {nme:18s} {val:10.0f}")
     print(f"   total              {v[:7].sum():10.0f}")
-    print("   factor split (same wave): diag16+rhs %.0f | wait W %.0f | panel %.0f | wait row %.0f | trailing %.0f" % tuple(v[8:13]))
+    print("   factor split (same wave): diag16+rhs %.0f | wait W %.0f | panel %.0f | wait row+WAR %.0f | trailing MFMA %.0f" % tuple(v[8:13]))
