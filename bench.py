@@ -387,6 +387,10 @@ def main():
             res["strong_scaling_base"] = base
             res["secondary_rank1"] = secondary_rank1(dev, ops)
             res["secondary_matrix_terms"] = secondary_matrix_terms(dev, ops)
+            big = secondary_matrix_terms(dev, ops, b=256, T=256, reps=3)       # configs[4]'s size: composition of batched kernels
+            big["workload"] = ("256 items, T=256: a8 / a9 as compositions (cooperative Cholesky, L^-1 by block columns from L "
+                               "(k_trtri), triangular products, column norms for the diagonal prior scale)")
+            res["secondary_matrix_terms_T256"] = big
             res["offline_r100"] = secondary_offline_r100(dev)
         if cpu is not None:
             res["cpu_baseline"] = cpu

@@ -377,7 +377,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_potrf(PotrfArgs a) {
   __syncthreads();   // every wave has loaded its tiles before anyone overwrites A
   PivotAcc pa;
   pa.init();
-  coop_factor<NB, false>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, A, T, T);
+  coop_factor<NB, false>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, A, T, T, nullptr,
+                         a.Linv ? a.Linv + (size_t)m * T * T : nullptr, T);   // + the diagonal blocks of L^-1 (k_trtri does the rest)
   int info;
   const double ld = coop_logdet_info(pa, wave, lane, red, redi, info);
   if (threadIdx.x == 0) {
@@ -387,6 +388,82 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_potrf(PotrfArgs a) {
   for (int idx = threadIdx.x; idx < T * T; idx += 64 * WAVES) {   // zeros above the diagonal blocks
     const int i = idx / T, j = idx % T;
     if ((j >> 4) > (i >> 4)) A[idx] = 0.0;
+  }
+}
+
+// Z = L^-1 from L and the inverses of its diagonal blocks (already sitting in Z's diagonal blocks): block column Kc of Z by ONE
+// wave - forward substitution by blocks,  Z_IK = -W_I sum_{K <= j < I} L_Ij Z_jK  (I = K + 1 .. NB - 1), the column's tiles in
+// registers (accumulator layout = the B operand of the next product), L and W read from memory in A-operand order.  The block
+// columns are independent: 16 waves per 256 x 256 matrix, each one pass over its part of L - instead of one more cooperative
+// factorisation per block column (k_coop_inv: NB redundant factorisations per matrix, 3.4 ms for 256 matrices of 256).
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_trtri(const double* __restrict__ Lall, double* __restrict__ Zall, int T, int b,
+                                                      const int32_t* __restrict__ info) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int w = blockIdx.x * WAVES + wave;
+  const int m = w / NB, Kc = w % NB;
+  if (m >= b || 16 * Kc >= T) return;
+  const double* L = Lall + (size_t)m * T * T;
+  double* Z = Zall + (size_t)m * T * T;
+  const int nb = (T + 15) >> 4;
+  d4 Zc[NB];                                       // Z_IK, I = Kc .. nb - 1 (statically indexed: slot I)
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    if (I == Kc) {                                 // diagonal block: W_K, read back in accumulator layout v[r] = X[g + 4 r][c]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r, col = 16 * I + c;
+        Zc[I][r] = (row < T && col < T) ? Z[(size_t)row * T + col] : ((row == col) ? 1.0 : 0.0);
+      }
+    } else {
+      Zc[I] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+  }
+#pragma unroll
+  for (int I = 1; I < NB; ++I) {
+    if (I > Kc && I < nb) {
+      d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < I; ++j) {
+        if (j >= Kc) {
+          double av[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {            // A operand of L_Ij: lane (g, c) holds L[16 I + c][16 j + 4 s + g]
+            const int row = 16 * I + c, col = 16 * j + 4 * s + g;
+            av[s] = (row < T) ? L[(size_t)row * T + col] : 0.0;
+          }
+          if (j & 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc1 = mfma(av[s], Zc[j][s], acc1);
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc0 = mfma(av[s], Zc[j][s], acc0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
+      double wv[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {                // A operand of W_I (diagonal block I of Z)
+        const int row = 16 * I + c, col = 16 * I + 4 * s + g;
+        wv[s] = (row < T && col < T) ? Z[(size_t)row * T + col] : ((row == col) ? 1.0 : 0.0);
+      }
+      d4 z = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) z = mfma_sub(wv[s], acc0[s], z);      // -W_I acc
+      Zc[I] = z;
+    }
+  }
+  const bool bad = info && info[m] != 0;
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + g + 4 * r, col = 16 * Kc + c;
+      if (row < T && col < T && I != Kc) Z[(size_t)row * T + col] = bad ? __builtin_nan("") : ((I > Kc) ? Zc[I][r] : 0.0);
+    }
   }
 }
 
@@ -477,8 +554,11 @@ int launch_coop_potrf(const PotrfArgs& a, hipStream_t st) {
   const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
   if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_potrf<NB>), lds)) return rc_;
   if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_inv<NB>), lds)) return rc_;
-  if (a.Linv) hipLaunchKernelGGL(k_coop_inv<NB>, dim3(a.b, NB), dim3(64 * WAVES), lds, st, a);
   hipLaunchKernelGGL(k_coop_potrf<NB>, dim3(a.b), dim3(64 * WAVES), lds, st, a);
+  if (a.Linv) {   // L^-1 from L: the factor kernel left the diagonal blocks' inverses in Linv, k_trtri fills in the block columns
+    const int waves = a.b * NB;
+    hipLaunchKernelGGL(k_trtri<NB>, dim3((waves + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, st, a.A, a.Linv, a.T, a.b, a.info);
+  }
   return launch_status();
 }
 
@@ -508,6 +588,7 @@ struct GemmArgs {
   int ldd = 0;
   long sD = 0;
   int boff = 0;                // first batch item of this launch (gridDim.y is capped at 65535: larger batches go in chunks)
+  int triA = 0;                // A (not transposed) is lower triangular: row tile ti only needs k < 16 (ti + 1)
 };
 
 // TRIP = k-steps whose operand loads are issued before the first MFMA of a trip.  TRIP = 24 covers Kd <= 96 in ONE
@@ -527,7 +608,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   double* C = a.C + (size_t)b1 * a.sC + (size_t)b2 * a.sC2;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
   const int row = 16 * ti + c, col = 16 * tj + c;
-  const int nk = (a.Kd + 3) / 4;
+  int nk = (a.Kd + 3) / 4;
+  if (a.triA && !a.tA) nk = min(nk, 4 * (ti + 1));
   for (int k0 = 0; k0 < nk; k0 += TRIP) {   // TRIP k-steps per trip: their 2 TRIP operand loads are issued before the first MFMA
     double av[TRIP], bv[TRIP];
 #pragma unroll
@@ -579,6 +661,29 @@ __global__ __launch_bounds__(256) void k_dot_batched(const double* __restrict__ 
   const double* y = Y + (size_t)blockIdx.x * sY;
   double s = 0.0;
   for (long i = threadIdx.x; i < n; i += 256) s = fma(x[i], y[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = (accumulate ? out[blockIdx.x] : 0.0) + scale * red[0];
+}
+
+// out[b] (+)= scale * sum_ij Z[b][i][j]^2 S[j][j]: trace(Sigma^-1 S) for a DIAGONAL prior scale S from Z = L^-1 alone
+__global__ __launch_bounds__(256) void k_colnorm_diag(const double* __restrict__ Z, const double* __restrict__ S, long sS, int T,
+                                                       double scale, int accumulate, double* out) {
+  __shared__ double red[256];
+  const double* z = Z + (size_t)blockIdx.x * T * T;
+  const double* sd = S + (size_t)blockIdx.x * sS;
+  double s = 0.0;
+  for (long i = threadIdx.x; i < (long)T * T; i += 256) {
+    const int r = (int)(i / T), cidx = (int)(i % T);
+    if (cidx <= r) {
+      const double v = z[i];
+      s = fma(v * v, sd[(size_t)cidx * T + cidx], s);
+    }
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -1735,6 +1840,7 @@ int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A
   if (rc) return rc;
   hipLaunchKernelGGL(k_lat_resid, dim3(b), dim3(256), 0, st, f_cur, f_prev, A, T, r);
   GemmArgs g1{Z, A, Y, T, T, T, T, T, T, tt, tt, tt, 1.0, 0.0, 0, 0};
+  g1.triA = 1;                                                                       // Z = L^-1 is lower triangular
   if ((rc = launch_gemm(g1, b, st))) return rc;
   GemmArgs g2{Y, covprev, Y2, T, T, T, T, T, T, tt, tt, tt, 1.0, 0.0, 0, 0};
   if ((rc = launch_gemm(g2, b, st))) return rc;
@@ -1742,6 +1848,7 @@ int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A
   hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, Y2, Y, tt, tt, tt, -0.5, 0, out);
   // mahal = || Z r ||^2 : z = Z r as a T x 1 GEMM into Y2
   GemmArgs g3{Z, r, Y2, T, 1, T, T, 1, 1, tt, (long)T, tt, 1.0, 0.0, 0, 0};
+  g3.triA = 1;
   if ((rc = launch_gemm(g3, b, st))) return rc;
   hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, Y2, Y2, tt, tt, (long)T, -0.5, 1, out);
   return launch_status();
@@ -1767,6 +1874,7 @@ int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_me
   if (rc) return rc;
   hipLaunchKernelGGL(k_sub_batched, dim3((unsigned)((tt + 255) / 256), std::min(b, 65535)), dim3(256), 0, st, M, m_mean, tt, prior_stride, tt, D, b);
   GemmArgs g1{Z, D, Y, T, T, T, T, T, T, tt, tt, tt, 1.0, 0.0, 0, 0};              // Y = L^{-1} D
+  g1.triA = 1;
   if ((rc = launch_gemm(g1, b, st))) return rc;
   if (m_r_cov) {                                                                     // sum (D R) o Sigma^{-1} D = sum (Y R) o Y
     GemmArgs g2{Y, m_r_cov, D, T, T, T, T, T, T, tt, prior_stride, tt, 1.0, 0.0, 0, 0};
@@ -1775,7 +1883,12 @@ int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_me
   } else {
     hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, Y, Y, tt, tt, tt, -0.5, 0, out);
   }
+  if (scale_is_diagonal) {   // the hot path's prior scale sigma I: trace(Sigma^{-1} S) = sum_j S_jj |Z e_j|^2, no product
+    hipLaunchKernelGGL(k_colnorm_diag, dim3(b), dim3(256), 0, st, Z, scale, prior_stride, T, -0.5, 1, out);
+    return launch_status();
+  }
   GemmArgs g3{Z, scale, Y, T, T, T, T, T, T, tt, prior_stride, tt, 1.0, 0.0, 0, 0};  // trace(Sigma^{-1} S) = sum (Z S) o Z
+  g3.triA = 1;
   if ((rc = launch_gemm(g3, b, st))) return rc;
   hipLaunchKernelGGL(k_dot_batched, dim3(b), dim3(256), 0, st, Y, Z, tt, tt, tt, -0.5, 1, out);
   return launch_status();

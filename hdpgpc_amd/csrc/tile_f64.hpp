@@ -758,7 +758,9 @@ __device__ __forceinline__ void coop_add_diag(d4 (&U)[Coop<NB>::NT], double shif
 template <int NB, int RHSMODE>
 __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbuf, double* Rbuf, double* Wbuf, double* scr,
                                               int wave, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n,
-                                              double* dvec = nullptr) {
+                                              double* dvec = nullptr, double* Wout = nullptr, int ldw = 0) {
+  // Wout (optional): the inverses W_K = L_KK^{-1} of the diagonal blocks go to the diagonal blocks of this [n, ldw] matrix -
+  // they ARE the diagonal blocks of L^{-1}; k_trtri (hgp_kernels.hip) fills in the rest from L.
   using C = Coop<NB>;
   constexpr bool RHS = (RHSMODE == 1);
   double zq = 0.0;
@@ -780,6 +782,13 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
       const d4 Wd = diag16(U[C::loc(K, qK)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
 #pragma unroll
       for (int s = 0; s < 4; ++s) Wbuf[s * 64 + lane] = Wd[s];
+      if (Wout != nullptr) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int row = 16 * K + c, col = 16 * K + 4 * s + g;      // Wd[s] = W[c][4 s + g]
+          if (row < n && col < n) Wout[(size_t)row * ldw + col] = Wd[s];
+        }
+      }
       if (RHS) {   // Z_K = W R_K
         const d4 rk = lds_tile_load(Rbuf, K, lane);
         d4 z = (d4){0.0, 0.0, 0.0, 0.0};
