@@ -267,6 +267,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only (used for the PMC passes)")
+    ap.add_argument("--no-offline", action="store_true", help="skip the record-100 include_batch secondary (kernel-trace runs: it is ~10^5 launches)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on a one-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--segments", type=int, default=0, help="override the batch size (rehearsals only; 0 = the named config)")
@@ -391,7 +392,8 @@ def main():
             big["workload"] = ("256 items, T=256: a8 / a9 as compositions (cooperative Cholesky, L^-1 by block columns from L "
                                "(k_trtri), triangular products, column norms for the diagonal prior scale)")
             res["secondary_matrix_terms_T256"] = big
-            res["offline_r100"] = secondary_offline_r100(dev)
+            if not args.no_offline:
+                res["offline_r100"] = secondary_offline_r100(dev)
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
-echo "[profile_bench] kernel trace $(date +%T)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/kt.log 2>&1 || { tail -5 $OUT/kt.log; exit 1; }
+echo "[profile_bench] kernel trace $(date +%T)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-offline > $OUT/kt.log 2>&1 || { tail -5 $OUT/kt.log; exit 1; }
 # one rocprofv3 run per counter group: FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950 ("exceeds the capabilities")
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64" \
@@ -18,3 +18,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VAL
   timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$i -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/pmc_$i.log 2>&1 || { echo "pass $i failed"; grep -v "^    @" $OUT/pmc_$i.log | tail -4; }
 done
 python3 $R/tools/summarize_profiles.py $OUT
+# the producer (member chains of the offline loop) on the first 600 beats of record 100: kernel trace
+echo "[profile_bench] offline loop kernel trace $(date +%T)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_offline -o kt -- python3 $R/tools/time_offline.py 600 > $OUT/kt_offline.log 2>&1 || tail -5 $OUT/kt_offline.log
+f=$(find $OUT/kt_offline -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/offline_kernel_stats.csv
+tail -60 $OUT/kt_offline.log | grep "include_batch on" || true
