@@ -81,6 +81,7 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         self.static_factor = self.dynamic_factor = 1.0                                        # GPI_HDP.py:181-182
         self.gamma, self.transAlpha, self.startAlpha, self.kappa = _HDP_HYP[hdp_hyp]           # GPI_HDP.py:274-291
         self.fixed_theta = None
+        self.rank1_scoring = False     # annealing=False only: carry chol(scale) by rank-1 updates instead of refactoring (GPI_model.py)
         self.train_elbo, self.resp_assigned, self.q = [], [], []
         self.T = 0
         self.x_train, self.y_train, self.y = [], torch.tensor([]), []
@@ -115,6 +116,7 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         g.internal_params, g.observation_params = gpmodel.internal_params, gpmodel.observation_params
         g.fixed_theta, g.noise_bounds, g.estimation_limit = gpmodel.fixed_theta, gpmodel.noise_bounds, gpmodel.estimation_limit
         g.theta_source = gpmodel.theta_source
+        g.rank1_scoring, g._Lobs = gpmodel.rank1_scoring, gpmodel._Lobs
         g.gp.fitted = gpmodel.gp.fitted
         return g
 

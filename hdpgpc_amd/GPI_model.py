@@ -153,6 +153,11 @@ class GPI_model:
         self.fitted = False
         self.fixed_theta = None        # (c, ell, noise) taken by fit_kernel_params instead of the gpytorch fit
         self.theta_source = None       # ... or an owner (GPI_HDP) whose `fixed_theta` is looked up at fit time
+        # BASELINE configs[4]: carry chol(scale) of the observation MNIW through its rank-1 recursion (GPI_model.py:1332-1336)
+        # instead of refactoring Sigma at every score.  Only exact when Sigma is a multiple of the scale, i.e. annealing off
+        # (the annealed Sigma_i adds a time-varying diagonal shift); off by default, see rank1_scale_factor below.
+        self.rank1_scoring = False
+        self._Lobs = None              # (observation_params object the factor belongs to, lower Cholesky factor of its scale)
         self.noise_bounds = (1e-10, 1e10)
         self._stk = {}
         self._pending = []
@@ -511,6 +516,8 @@ class GPI_model:
             new_obs = self.observation_params.posterior(1, self.y_train[-1], self.f_star_sm[-1], defer=infos)
             if bool(torch.cat(infos).any()):             # GPI_model.py:1068-1071: keep the previous distributions
                 new_int, new_obs = self.internal_params, self.observation_params
+            elif self._rank1_on():
+                self._rank1_advance(new_obs)
         else:
             new_int, new_obs = self.internal_params, self.observation_params
         self.internal_params, self.observation_params = new_int, new_obs
@@ -526,6 +533,33 @@ class GPI_model:
             self.Gamma.append(Gamma_)
             self.C.append(new_obs.get_mean())
             self.Sigma.append(Sigma_)
+
+    def _rank1_on(self):
+        return (self.rank1_scoring or bool(getattr(self.theta_source, "rank1_scoring", False))) and not self.annealing
+
+    def _rank1_advance(self, new_obs):
+        """scale' = ((n0 - 2) scale + e e^T) / (n0 - 1), e = y - f_sm  (GPI_model.py:1332-1336): its Cholesky factor from the
+        previous one by ONE rank-1 update, O(T^2) (hgp_chol_rank1_f64) - the consumer of BASELINE configs[4]'s kernel."""
+        old = self.observation_params
+        n0 = float(old.n0)
+        if self._Lobs is None or self._Lobs[0] is not old:      # (re)start the recursion from a full factorisation
+            L, info = ops.potrf_batched(old.scale.contiguous(), 0.0, 0.0)
+            if bool(info.any()):
+                self._Lobs = None
+                return
+            self._Lobs = (old, L[0])
+        e = (self.y_train[-1] - self.f_star_sm[-1]).reshape(1, -1).contiguous()
+        L1, info = ops.chol_rank1(self._Lobs[1].contiguous(), e, alpha=(n0 - 2.0) / (n0 - 1.0), beta=1.0 / (n0 - 1.0))
+        self._Lobs = None if bool(info.any()) else (new_obs, L1)
+
+    def rank1_scale_factor(self):
+        """(L, c) with Sigma[-1] = c L L^T when the tracked factor belongs to the current observation distribution and the last
+        Sigma is exactly a multiple of its scale (N > 1, no annealing); None otherwise (callers refactor)."""
+        if (not self._rank1_on() or self._Lobs is None or self._Lobs[0] is not self.observation_params
+                or self.N <= 1 or not self.N < self.estimation_limit):
+            return None
+        n0 = float(self.observation_params.n0)
+        return self._Lobs[1], n0 / (n0 - 2.0)
 
     def backwards(self, h=1.0):
         """GPI_model.py:687-703 + GPI.backward (GPI.py:240-270): full RTS pass over the filtered states."""
@@ -940,6 +974,12 @@ class GPI_model:
         fn = 1e-2 * float(torch.mean(torch.diagonal(self.Sigma[0]))) if first else 0.0
         T = self.x_basis.shape[0]
         if x.shape == self.x_basis.shape and torch.equal(x, self.x_basis):
+            last = mean is None and (i is None or i == -1 or i >= len(self.indexes)) and not first and not proj
+            fac = self.rank1_scale_factor() if last else None
+            if fac is not None:      # Sigma[-1] = c L L^T with L carried by rank-1 updates: |L^-1 d|^2 / c, no factorisation.
+                # (the reference's 1e-8 mean|diag| jitter of _chol_spd is not applied: relative change of the score <= 1e-8 cond)
+                quad = ops.trsv_lower_quad(fac[0], (y.reshape(-1) - m.reshape(-1)).contiguous()) / fac[1]
+                return -0.5 * quad - 0.5 * y.shape[1] * LOG2PI
             items = ops.build_items([0], [fn], [1])
             quad, _, info = ops.score_groups(y, m.reshape(1, T).contiguous(), S.reshape(1, T, T).contiguous(), *items)
         else:

@@ -61,7 +61,7 @@ class OnlineLoop:
         On the basis grid pred_dist short-circuits (GPI.py:467-468) and the M evaluations are one launch."""
         models = self.gpmodels[ld]
         xb = models[0].x_basis
-        if x.shape == xb.shape and bool(torch.equal(x, xb)):
+        if x.shape == xb.shape and bool(torch.equal(x, xb)) and not any(g.rank1_scale_factor() is not None for g in models):
             sel = [g._select(-1) for g in models]
             means = torch.stack([g._mean_of(ci, fi).reshape(-1) for g, (ci, fi) in zip(models, sel)]).contiguous()
             Sig = torch.stack([g.Sigma[ci] for g, (ci, _) in zip(models, sel)]).contiguous()

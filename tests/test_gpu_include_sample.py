@@ -34,3 +34,50 @@ def test_include_sample_r102_t256():
     wall = time.time() - t0
     worst = compare_online(g, tr, 1e-8)
     print(f"include_sample, 24 beats T=256: {wall:.2f} s (reference {float(g['secs'].sum()):.1f} s), worst {worst:.2e}")
+
+
+def test_online_rank1_factor_tracking_t256():
+    """BASELINE configs[4] names the rank-1 Cholesky update kernel as part of the online path at T = 256.  Its consumer: with
+    annealing off Sigma_i is an exact multiple of the observation MNIW's scale, whose factor then follows the recursion
+    scale' = ((n0 - 2) scale + e e^T) / (n0 - 1) by one hgp_chol_rank1_f64 per absorbed beat, and the beat's score under a
+    cluster's last state is |L^-1 d|^2 / c - no factorisation.  Stated tolerance: the reference's 1e-8 mean|diag|
+    jitter of _chol_spd is not applied on this path, so scores agree with the refactoring path to 1e-6 relative, not 1e-9;
+    the clustering decisions must be identical."""
+    import numpy as np
+    import hdpgpc.GPI_HDP as hdpgp
+    g = golden("include_sample_r102_t256_n24.npz")
+    std, std_dif, bs0, bs1, bg0, bg1 = (float(v) for v in g["estimators"])
+    data = np.asarray(g["y"], dtype=np.float64)[:, :, None]
+    T = data.shape[1]
+    xb = np.arange(float(T))[:, None]
+
+    def run(rank1):
+        sw = hdpgp.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, ini_lengthscale=3.0, bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif,
+                           ini_sigma=std, ini_outputscale=300.0, noise_warp=std * 0.1, bound_sigma=(bs0, bs1), bound_gamma=(bg0, bg1),
+                           bound_noise_warp=(std * 0.01, std * 0.02), annealing=False, verbose=False, max_models=100,
+                           bayesian_params=True, free_deg_MNIV=20)
+        sw.fixed_theta = tuple(float(v) for v in g["theta_inject"])
+        sw.rank1_scoring = rank1
+        used = 0
+        for i in range(data.shape[0]):
+            sw.include_sample(xb, data[i], with_warp=False)
+            used += sum(1 for m in sw.gpmodels[0] if m.rank1_scale_factor() is not None)
+        return sw, used
+
+    a, used_a = run(False)
+    b, used_b = run(True)
+    assert used_a == 0 and used_b > 0                        # the tracked factors were live on the second run
+    assert [int(r[-1]) for r in a.resp_assigned] == [int(r[-1]) for r in b.resp_assigned] and a.M == b.M
+    qa, qb = a.q[-1].cpu().numpy(), b.q[-1].cpu().numpy()
+    fin = np.isfinite(qa)
+    assert np.array_equal(fin, np.isfinite(qb))
+    err = float(np.max(np.abs(qa[fin] - qb[fin]) / np.abs(qa[fin])))
+    print(f"rank-1 tracked scoring vs refactoring, T=256, 24 beats: max relative difference {err:.2e}")
+    assert err <= 1e-6
+    # and the factor itself against a full factorisation of the scale it claims to factor
+    for m in b.gpmodels[0]:
+        fac = m.rank1_scale_factor()
+        if fac is not None:
+            L = fac[0].cpu().numpy()
+            S = m.observation_params.scale.cpu().numpy()
+            assert np.max(np.abs(L @ L.T - S)) <= 1e-10 * np.max(np.abs(S))
