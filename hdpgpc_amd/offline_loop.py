@@ -79,7 +79,8 @@ class OfflineLoop:
         """GPI_HDP.py:1076-1089: an empty cluster in front of a filled last one is swapped with it; an empty last one next to
         another empty one ends the loop."""
         per = self._counts(resp)
-        self._log("Group responsability estimated: " + str(per.numpy().astype(np.int64)))
+        if self.verbose:
+            self._log("Group responsability estimated: " + str(per.numpy().astype(np.int64)))
         if bool(torch.any(per[:-1] < 1.0)):
             if per[-1] >= 1.0:
                 resp, respPair = self.refill_resp(resp, respPair)
@@ -212,7 +213,7 @@ class OfflineLoop:
         elbo_lds = 0.0
         for i in range(self.n_outputs):
             elbo_lds += self.full_LDS_elbo(gpmodels[i], sum_resp, one_sample=one_sample) * float(frac[i])
-        if verb:
+        if verb and self.verbose:
             self._log("Sum resp_temp: " + str(sum_resp.int().numpy()) + " - Total samples: " + str(int(sum_resp.sum())))
             self._log(f"Q_em: {q_bas:.2f}, Q_lat: {elbo_latent:.2f}, Elbo_linear: {elbo_lin:.2f}, Elbo_LDS: {elbo_lds:.2f}")
         return q_bas, (elbo_lin + elbo_lds + elbo_latent) if self.hmm_switch else elbo_latent
@@ -664,7 +665,8 @@ class OfflineLoop:
             q_bas, elbo_bas = self.compute_q_elbo(resp, respPair, self.weight_mean(q), self.weight_mean(q_lat), self.gpmodels,
                                                   self.M, snr='saved', post=resp.shape[1] > self.M)
             i += 1
-            self._log("First resp: " + str(self._counts(resp).int().numpy()))
+            if self.verbose:
+                self._log("First resp: " + str(self._counts(resp).int().numpy()))
         else:
             q_bas, elbo_bas = self.compute_q_elbo(resp, respPair, self.weight_mean(q), self.weight_mean(q_lat), self.gpmodels,
                                                   self.M, snr='saved', post=False)
