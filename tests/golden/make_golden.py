@@ -675,24 +675,25 @@ def _pack_trace(out, N, order, elbo, qall, fpw, em):
 
 
 # ------------------------------------- SURVEY 8b Face 1: the offline variational loop, GPI_HDP.include_batch
-def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5):
+def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5, leads=None):
     """Run the reference's include_batch exactly as hdpgpc/tests/test_offline.py:32-79 drives it (kernel fit replaced by the
     theta injection above) and record a TRACE of what the loop decided and computed: every ELBO evaluation
     (GPI_HDP.compute_q_elbo), every assignment returned by estimate_q_all, every full_pass_weighted, and per EM
     iteration (variational_local_terms_batch) the assignments and the q / q_lat matrices.  Data only."""
-    data = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:n, :, [lead]]
-    N, T, _ = data.shape
+    leads = [lead] if leads is None else list(leads)       # several leads: hdpgpc/tests/test_offline_multi_output.py
+    data = np.ascontiguousarray(np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:n, :, leads])
+    N, T, D = data.shape
     std, std_dif, bound_sigma, bound_gamma = compute_estimators_LDS(data)
     xb = np.arange(float(T))[:, None]
     x_trains = np.array([xb] * N)
-    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic",
+    sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=D, kernels=None, model_type="dynamic",
                      ini_lengthscale=3.0, bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std,
                      ini_outputscale=300.0, noise_warp=std * 0.1, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
                      bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False, method_compute_warp="greedy",
                      verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
                      inducing_points=False, reestimate_initial_params=True, n_explore_steps=n_explore, free_deg_MNIV=5)
     order, elbo, qall, fpw, em, wall, _ = _trace_loop(sw, lambda: sw.include_batch(x_trains, data, warp=False))
-    out = {"y": data[..., 0], "x_basis": xb[:, 0], "estimators": np.array([std, std_dif, *bound_sigma, *bound_gamma]),
+    out = {"y": data[..., 0] if D == 1 else data, "x_basis": xb[:, 0], "estimators": np.array([std, std_dif, *bound_sigma, *bound_gamma]),
            "theta_inject": np.array(THETA_INJECT), "n_explore": np.array(n_explore), "wall_s": np.array(wall),
            "M_final": np.array(sw.M), "train_elbo": np.array([float(e) for e in sw.train_elbo]),
            "resp_assigned": np.stack([npy(r).astype(np.int16) for r in sw.resp_assigned]),
@@ -701,6 +702,23 @@ def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5):
            "gamma_def": np.array(float(sw.ini_gamma_def)),
            "counts_final": np.array([len(g.indexes) for g in sw.gpmodels[0]], dtype=np.int64)}
     _pack_trace(out, N, order, elbo, qall, fpw, em)
+    if D > 1:
+        # the reference's own sensitivity (lead 1 of record 102 is ill-conditioned): the same run on inputs perturbed by 1e-15
+        data_p = data * (1.0 + 1e-15 * np.random.default_rng(0).standard_normal(data.shape))
+        sw2 = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=D, kernels=None, model_type="dynamic",
+                          ini_lengthscale=3.0, bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std,
+                          ini_outputscale=300.0, noise_warp=std * 0.1, bound_sigma=bound_sigma, bound_gamma=bound_gamma,
+                          bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False, method_compute_warp="greedy",
+                          verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
+                          inducing_points=False, reestimate_initial_params=True, n_explore_steps=n_explore, free_deg_MNIV=5)
+        o2, e2, qa2, f2, em2, _, _ = _trace_loop(sw2, lambda: sw2.include_batch(x_trains, data_p, warp=False))
+        rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(np.asarray(b)))), 1e-300))  # noqa: E731
+        same = o2 == order and all(np.array_equal(a, b) for a, b in zip(qa2, qall))
+        out["ref_pert_same_decisions"] = np.array(same)
+        if same:
+            out["ref_sens"] = np.array(max([rel(a[1:3], b[1:3]) for a, b in zip(e2, elbo)] + [rel(a[3:], b[3:]) for a, b in zip(f2, fpw)] +
+                                           [max(rel(a[1], b[1]), rel(a[2], b[2])) for a, b in zip(em2, em)]))
+            print("reference sensitivity of the traced numbers to a 1e-15 input perturbation:", float(out["ref_sens"]))
     if n is None or n > 500:          # the full record's beats are already a fixture (mitbih100_lead0.npz)
         del out["y"]
     np.savez_compressed(os.path.join(OUT, f"include_batch_{tag}.npz"), **out)
@@ -832,6 +850,8 @@ if __name__ == "__main__":
         gen_producer_extra()
     if "ib80" in which:
         gen_include_batch("r100_n80", "100", 80)
+    if "ib2" in which:
+        gen_include_batch("r102_2leads_n100", "102", 100, leads=(0, 1), n_explore=5)
     if "ib100" in which:
         gen_include_batch("r100", "100", None)
     if "learn" in which:

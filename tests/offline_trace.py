@@ -8,11 +8,12 @@ def build_model(g, y):
     import hdpgpc.GPI_HDP as hdpgp
 
     std, std_dif, bs0, bs1, bg0, bg1 = (float(v) for v in g["estimators"])
-    data = np.asarray(y, dtype=np.float64)[:, :, None]
-    N, T, _ = data.shape
+    data = np.asarray(y, dtype=np.float64)
+    data = data[:, :, None] if data.ndim == 2 else data          # [N, T] one lead, [N, T, D] several
+    N, T, D = data.shape
     xb = np.arange(float(T))[:, None]
     x_trains = np.array([xb] * N)
-    sw = hdpgp.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
+    sw = hdpgp.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=D, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
                        bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std, ini_outputscale=300.0, noise_warp=std * 0.1,
                        bound_sigma=(bs0, bs1), bound_gamma=(bg0, bg1), bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False,
                        method_compute_warp="greedy", verbose=False, hmm_switch=True, max_models=100, mode_warp="rough",
@@ -144,7 +145,8 @@ def compare_trace(g, sw, tr, q_tol=1e-8, n_em=None):
         assert _rel(sw.q_last.cpu().numpy(), g["q_last"]) <= q_tol and _rel(sw.q_lat_last.cpu().numpy(), g["q_lat_last"]) <= q_tol
     elif n_em is None:
         assert sw.M == int(g["M_final"])
-        assert np.array_equal(np.array([len(m.indexes) for m in sw.gpmodels[0]]), g["counts_final"])
+        for lead in sw.gpmodels:
+            assert np.array_equal(np.array([len(m.indexes) for m in lead]), g["counts_final"])
         ra = np.stack([r.numpy().astype(np.int16) for r in sw.resp_assigned])
         assert np.array_equal(ra, g["resp_assigned"])
         assert _rel(np.array(sw.train_elbo), g["train_elbo"]) <= q_tol

@@ -56,3 +56,14 @@ def test_cluster_new_batch_learning_two_leads():
     sw, tr = run_cluster_learning(g)
     worst = compare_trace(g, sw, tr, q_tol=max(1e-8, 50.0 * float(g["ref_sens"])))
     print(f"cluster_new_batch(learning=True), 2 leads: {len(tr['order'])} traced calls, worst relative error {worst:.2e}")
+
+
+def test_include_batch_two_leads():
+    """hdpgpc/tests/test_offline_multi_output.py's configuration (both leads, one model per (lead, cluster), SNR-weighted
+    combination of the leads) on the first 100 beats of record 102: 334 traced calls, 8 EM iterations, six clusters.  Gate as
+    for the other two-lead fixtures: 50 x the reference's own change under a sub-ulp perturbation of the inputs."""
+    g = golden("include_batch_r102_2leads_n100.npz")
+    assert bool(g["ref_pert_same_decisions"])
+    sw, tr = run_traced(g, g["y"])
+    worst = compare_trace(g, sw, tr, q_tol=max(1e-8, 50.0 * float(g["ref_sens"])))
+    print(f"include_batch, two leads: {len(tr['order'])} traced calls, worst relative error {worst:.2e}")

@@ -52,3 +52,11 @@ def test_cluster_new_batch_learning_two_leads_cpu(monkeypatch):
     g = golden("cluster_learning_r102_2leads.npz")
     sw, tr = run_cluster_learning(g)
     compare_trace(g, sw, tr, q_tol=max(1e-8, 50.0 * float(g["ref_sens"])))
+
+
+def test_include_batch_two_leads_cpu(monkeypatch):
+    """Host logic of include_batch with two leads against the reference's trace (record 102, 100 beats)."""
+    cpu_double.install(monkeypatch)
+    g = golden("include_batch_r102_2leads_n100.npz")
+    sw, tr = run_traced(g, g["y"])
+    compare_trace(g, sw, tr, q_tol=max(1e-8, 50.0 * float(g["ref_sens"])))
