@@ -78,6 +78,13 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         self.share_gp, self.reduce_outputs, self.reduce_outputs_ratio = share_gp, reduce_outputs, reduce_outputs_ratio
         self.f_ind_old = torch.zeros(self.M, dtype=torch.int64)
         self.noise_warp, self.mode_warp, self.method_compute_warp = noise_warp, mode_warp, method_compute_warp
+        self.bound_noise_warp_def = tuple(bound_noise_warp[0]) if isinstance(bound_noise_warp, list) else tuple(bound_noise_warp)
+        self.recursive_warp_def = bool(_first(recursive_warp))
+        self.x_basis_warp_def = self.x_basis_ini if x_basis_warp is None else np.asarray(
+            x_basis_warp[0] if isinstance(x_basis_warp, list) else x_basis_warp, dtype=np.float64).reshape(-1, 1)
+        self.warp = False
+        self.wp_sys = [[self.create_wp_sys_default() for _ in range(self.M)] for _ in range(self.n_outputs)]   # GPI_HDP.py:221-226
+        self._warp_cache_full = {}
         self.static_factor = self.dynamic_factor = 1.0                                        # GPI_HDP.py:181-182
         self.gamma, self.transAlpha, self.startAlpha, self.kappa = _HDP_HYP[hdp_hyp]           # GPI_HDP.py:274-291
         self.fixed_theta = None
@@ -103,6 +110,12 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         gp.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
         gp.theta_source = self
         return gp
+
+    def create_wp_sys_default(self):
+        """GPI_HDP.py:573-583: a fresh time-warp fitter with the default options (one per lead and cluster)."""
+        from .amtgp_warping_system import Warping_system
+        return Warping_system(self.x_basis_warp_def, self.noise_warp, self.bound_noise_warp_def, recursive=self.recursive_warp_def,
+                              bayesian=self.bayesian_params, mode=self.mode_warp, device=self._default_device)
 
     def gpmodel_deepcopy(self, gpmodel):
         """GPI_HDP.py:4037-4064: a new model object with the same kernel hyper-parameters, priors and (shared, immutable)
@@ -267,7 +280,7 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         # one fresh default model per (lead, class) (= the reference's deep copy of model 0 re-initialised, reinit_LDS / reinit_GP);
         # the D x M chains are independent: they run side by side (chain_batch.py)
         self.gpmodels = [[self.create_gp_default() for _ in range(M)] for _ in range(self.n_outputs)]
-        outs = iter(self._passes(x, y, [(self.gpmodels[ld][m], ld, resp[:, m]) for ld in range(self.n_outputs) for m in range(M)]))
+        outs = iter(self._passes(x, y, [(self.gpmodels[ld][m], y[:, :, [ld]], resp[:, m]) for ld in range(self.n_outputs) for m in range(M)]))
         for ld in range(self.n_outputs):
             for m in range(M):
                 out = next(outs)

@@ -253,13 +253,14 @@ class OfflineLoop:
             g.reinit_GP(save_last=False)
         return g
 
-    def _one_member_scores(self, gp_src, x, y, ld, beat, include=True):
-        """Scores of all segments under a copy of ``gp_src`` that has seen only segment ``beat`` (as member number 0:
-        GPI_HDP.py:1294, 1581): one Kalman step + one shared-covariance launch.  Returns (q [N], the model)."""
+    def _one_member_scores(self, gp_src, x, y, ld, beat, include=True, ycol=None):
+        """Scores of all segments (``ycol``: as warped for this column; default the raw lead) under a copy of ``gp_src`` that has
+        seen only the RAW segment ``beat`` (as member number 0: GPI_HDP.py:1294, 1581): one Kalman step + one shared-covariance
+        launch.  Returns (q [N], the model)."""
         g = self._fresh_copy(gp_src)
         if include:
             g.include_weighted_sample(0, x[beat], x[beat], y[beat, :, [ld]], h=1.0)
-        return g.compute_sq_err_all(x, y[:, :, [ld]]), g
+        return g.compute_sq_err_all(x, y[:, :, [ld]] if ycol is None else ycol), g
 
     def _pick_representatives(self, resp_temp, q_w_simple, M, f_ind_old):
         """GPI_HDP.py:1404-1429 / 1760-1785: per cluster the member with the best one-member score that is not already the
@@ -291,6 +292,8 @@ class OfflineLoop:
         resp_temp, respPair_temp = self._assign(self.weight_mean(q_, snr_aux), startPi)
         reorder = torch.argsort(self._counts(resp_temp), descending=True)
         resp_temp = resp_temp[:, reorder].clone()                              # quirk: the pair table keeps the old order
+        f_ind_old = self.f_ind_old if f_ind_old is None else f_ind_old
+        Yw, liks = self.warp_batch_by_resp_amtgp_cached(x_trains, y_trains, resp_temp, f_ind_old)   # columns in f_ind_old's order
         gpmodels_temp = [[] for _ in range(D)]
         plan = []                                     # (ld, m, r, model, kind): kind 0 unchanged, 1 changed, 2 new with members, 3 new empty
         for ld in range(D):
@@ -313,7 +316,8 @@ class OfflineLoop:
                     kind = 2 if len(members) > 0 else 3
                 plan.append((ld, m, r, gp, kind))
                 gpmodels_temp[ld].append(gp)
-        outs = iter(self._passes(x_trains, y_trains, [(gp, ld, resp_temp[:, m]) for ld, m, r, gp, kind in plan if kind in (1, 2)]))
+        outs = iter(self._passes(x_trains, y_trains, [(gp, self._ycol(Yw, y_trains, ld, r), resp_temp[:, m])
+                                                      for ld, m, r, gp, kind in plan if kind in (1, 2)]))
         for ld, m, r, gp, kind in plan:
             if kind in (1, 2):
                 out = next(outs)
@@ -321,7 +325,9 @@ class OfflineLoop:
                 if out is None:                       # no members: the previous columns (quirk: of the table being filled, for q_lat of a new model)
                     out = (q_[:, r, ld], (q_lat_ if kind == 1 else q_lat)[:, r, ld])
                 q[:, m, ld], q_lat[:, m, ld] = out
-                snr_aux[:, m, ld] = self.compute_snr(y_trains[:, :, ld], gp)
+                if liks is not None:
+                    q[:, m, ld] += liks[:, r, ld]
+                snr_aux[:, m, ld] = self.compute_snr(self._ylead(Yw, y_trains, ld, r), gp)
             elif kind == 0:
                 q[:, m, ld] = q_[:, r, ld]
                 q_lat[:, m, ld] = q_lat_[:, r, ld]
@@ -354,11 +360,69 @@ class OfflineLoop:
         self._log("Bad estimation")
         return resp, respPair, q_, q_lat_, snr_, gpmodels
 
+    # ------------------------------------------------------------------ warping inside the loop (GPI_HDP.py:3412-3525)
+    def warp_batch_by_resp_amtgp_cached(self, x, y, resp_temp, f_ind_old=None, train_iter=50, batch_size=128):
+        """Every segment warped onto the representative segment of every cluster column: (Yw [N, T, D, M], liks [N, M, D]); with
+        ``warp=False`` both are None (the reference's 4-D tensor is then a broadcast view of y and its liks are zeros).
+        One template = the representative f_ind_old[m] of column m on lead ld; its N warps are fitted in batches of 128 by
+        hgp_warp_batch_f64 (Warping_system.compute_warp_batch) and scored by the warp prior (a11); templates are cached by
+        (lead, representative) for the life of the model, as in the reference."""
+        if not self.warp:
+            return None, None
+        f_ind_old = self.f_ind_old if f_ind_old is None else f_ind_old
+        N, T, D = y.shape
+        M = resp_temp.shape[1]
+        Yw = torch.empty((N, T, D, M), dtype=f64, device=self.device)
+        liks = torch.zeros((N, M, D), dtype=f64, device=self.device)
+        theta = float(self.ini_lengthscale)                      # kernel_def's length-scale (GPI_HDP.py:3498)
+        noise = float(np.sqrt(self.ini_sigma_def))
+        for ld in range(D):
+            for m in range(M):
+                ref = int(f_ind_old[m])
+                key = (ld, ref)
+                if key not in self._warp_cache_full:
+                    warper = self.wp_sys[ld][min(m, len(self.wp_sys[ld]) - 1)]
+                    x0 = x[ref].reshape(-1)
+                    y_model = y[ref, :, [ld]]
+                    yw_all = torch.zeros((N, T), dtype=f64, device=self.device)
+                    lik_all = torch.zeros(N, dtype=f64, device=self.device)
+                    for s0 in range(0, N, batch_size):
+                        idx = slice(s0, min(s0 + batch_size, N))
+                        xwB, ywB, likB, _ = warper.compute_warp_batch(x0, y[idx][:, :, [ld]], y_model, theta=theta,
+                                                                      noise=torch.full((T,), noise, dtype=f64), train_iter=train_iter)
+                        base = self.wp_sys[ld][-1].warp_gp.log_sq_error_batch(x0, xwB[:, :, 0])
+                        yw_all[idx] = ywB[:, :, 0]
+                        lik_all[idx] = likB + base
+                    self._warp_cache_full[key] = (yw_all, lik_all)
+                yw_all, lik_all = self._warp_cache_full[key]
+                Yw[:, :, ld, m] = yw_all
+                liks[:, m, ld] = lik_all
+        return Yw, liks
+
+    @staticmethod
+    def _ycol(Yw, y, ld, m):
+        """Observations cluster column m scores / absorbs on lead ld, [N, T, 1]."""
+        return y[:, :, [ld]] if Yw is None else Yw[:, :, [ld], m]
+
+    @staticmethod
+    def _ylead(Yw, y, ld, m):
+        return y[:, :, ld] if Yw is None else Yw[:, :, ld, m]
+
+    @staticmethod
+    def select_assigned_warp(Yw, y, resp, order=None):
+        """GPI_HDP.py:3519-3525: every segment as warped onto ITS cluster's representative, [N, T, D]."""
+        if Yw is None:
+            return y
+        if order is not None:
+            Yw = Yw[:, :, :, order.to(Yw.device)]
+        z = torch.argmax(resp, dim=1).to(Yw.device)
+        return torch.gather(Yw, 3, z[:, None, None, None].expand(-1, Yw.shape[1], Yw.shape[2], 1)).squeeze(3)
+
     def _passes(self, x, y, specs):
-        """full_pass_weighted of many (model, lead, membership column) at once: the chains do not depend on each other, so they
+        """full_pass_weighted of many (model, observations [N, T, 1], membership column) at once: the chains do not depend on each other, so they
         advance side by side (chain_batch.py).  Returns per spec (q, q_lat), or None for a cluster without members (the caller
         keeps its previous columns, GPI_model.py:385-386).  ``_note_full_pass`` sees every result in spec order."""
-        jobs = [chain_batch.Job(gp, x, y[:, :, [ld]], col) for gp, ld, col in specs]
+        jobs = [chain_batch.Job(gp, x, ycol, col) for gp, ycol, col in specs]
         chain_batch.run(jobs)
         return [j.out if len(j.active) else None for j in jobs]
 
@@ -393,15 +457,18 @@ class OfflineLoop:
         x, y = x_trains, y_trains
         N, D, dev = y.shape[0], self.n_outputs, self.device
         empty_estimation = False
+        Yw, liks = self.warp_batch_by_resp_amtgp_cached(x, y, resp, self.f_ind_old)
         if float(torch.mean(q_)) == 0.0:                     # nothing scored yet: cluster 0 takes the whole batch
             snr_ = torch.zeros((N, M, D), dtype=f64, device=dev)
             if self.share_gp and D > 1:
                 raise NotImplementedError("share_gp with several leads is not part of this build")
             firsts = [self.create_gp_default() for _ in range(D)]
-            for ld, out in enumerate(self._passes(x, y, [(firsts[ld], ld, resp[:, 0]) for ld in range(D)])):
+            for ld, out in enumerate(self._passes(x, y, [(firsts[ld], self._ycol(Yw, y, ld, 0), resp[:, 0]) for ld in range(D)])):
                 self._note_full_pass(resp[:, 0], out)
                 q_[:, 0, ld], q_lat_[:, 0, ld] = out
-                snr_[:, 0, ld] = self.compute_snr(y[:, :, ld], firsts[ld])
+                if liks is not None:
+                    q_[:, 0, ld] += liks[:, 0, ld]
+                snr_[:, 0, ld] = self.compute_snr(self._ylead(Yw, y, ld, 0), firsts[ld])
                 self.gpmodels[ld][0] = firsts[ld]
         reallocate = False
         indexes_ = []
@@ -415,7 +482,9 @@ class OfflineLoop:
         for ld in range(D):
             for m in range(M):
                 q_simple[:, m, ld], _ = self._one_member_scores(self.gpmodels[ld][m], x, y, ld, int(f_ind_old[m]),
-                                                                include=len(indexes_[m]) > 0)
+                                                                include=len(indexes_[m]) > 0, ycol=self._ycol(Yw, y, ld, m))
+                if liks is not None:
+                    q_simple[:, m, ld] += liks[:, m, ld]
 
         if M > 1:
             q_aux, snr_aux = q_simple.clone(), snr_.clone()
@@ -435,13 +504,15 @@ class OfflineLoop:
                     gp = self._fresh_copy(self.gpmodels[ld][r]) if changed else self.gpmodels[ld][r]
                     plan.append((ld, m, r, gp, changed))
                     gpmodels_temp[ld].append(gp)
-            outs = iter(self._passes(x, y, [(gp, ld, resp_temp[:, m]) for ld, m, r, gp, changed in plan if changed]))
+            outs = iter(self._passes(x, y, [(gp, self._ycol(Yw, y, ld, r), resp_temp[:, m]) for ld, m, r, gp, changed in plan if changed]))
             for ld, m, r, gp, changed in plan:
                 if changed:
                     out = next(outs)
                     self._note_full_pass(resp_temp[:, m], out)
                     q[:, m, ld], q_lat[:, m, ld] = out if out is not None else (q[:, r, ld], q_lat[:, r, ld])
-                    snr_aux[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
+                    if liks is not None:
+                        q[:, m, ld] += liks[:, r, ld]
+                    snr_aux[:, m, ld] = self.compute_snr(self._ylead(Yw, y, ld, r), gp)
                 else:
                     q[:, m, ld] = q_[:, r, ld].clone()                    # quirk: q_lat keeps column m of the old table
                     snr_aux[:, m, ld] = snr_[:, r, ld].clone()
@@ -458,7 +529,7 @@ class OfflineLoop:
                 if q_bas + elbo_bas < q_bas_post + elbo_post and q_bas != q_bas_post:
                     self._log("Reallocating beats into existing groups.")
                     self.gpmodels = gpmodels_temp
-                    self.y_train = y
+                    self.y_train = self.select_assigned_warp(Yw, y, resp_temp, reorder)
                     self.f_ind_old = self._pick_representatives(resp_temp, self.weight_mean(q_simple, snr_aux), M, f_ind_old)
                     self.snr_norm = self.normalize_snr(snr_aux)
                     return resp_temp, respPair_temp, q, q_lat, snr_aux, True
@@ -546,9 +617,13 @@ class OfflineLoop:
                 last = near(f_new)
                 step += 1
                 self._log(f"Step {step}/{n_steps}- Trying to divide: {m_chosen} with beat {f_new}")
+                Yp, lp = self.warp_batch_by_resp_amtgp_cached(x, y, resp_, P["f_ind_old_temp"])     # + the column warped onto the seed
                 for ld in range(D):
-                    q_simple_[:, -1, ld], g1 = self._one_member_scores(self.gpmodels[ld][m_chosen], x, y, ld, f_new)
-                    snr_aux[:, -1, ld] = self.compute_snr(y[:, :, ld], g1)
+                    q_simple_[:, -1, ld], g1 = self._one_member_scores(self.gpmodels[ld][m_chosen], x, y, ld, f_new,
+                                                                       ycol=self._ycol(Yp, y, ld, -1))
+                    if lp is not None:
+                        q_simple_[:, -1, ld] += lp[:, -1, ld]
+                    snr_aux[:, -1, ld] = self.compute_snr(self._ylead(Yp, y, ld, -1), g1)
                 P["q_simple_"] = q_simple_
                 resp_temp, respPair_temp = self._assign(self.weight_mean(q_simple_, snr_aux), startPi)
             else:
@@ -559,6 +634,7 @@ class OfflineLoop:
                 snr_aux[:, -1, :] = torch.min(snr_aux) * 2.0
                 q__[f_new, -1, :] = 0.0
                 resp_temp, respPair_temp = self._assign(self.weight_mean(q__, snr_aux), startPi)
+                Yp, lp = Yw, liks                    # (the reference keeps the round's warps on this path)
             reorder = torch.argsort(self._counts(resp_temp), descending=True)
             resp_temp = resp_temp[:, reorder]
             gpmodels_temp = [[] for _ in range(D)]
@@ -575,11 +651,12 @@ class OfflineLoop:
                     plan.append((ld, m, r, gp, rebuild))
                     gpmodels_temp[ld].append(gp)
             P.update(q=q, q_lat=q_lat, snr_aux=snr_aux, q__=q__, q_lat__=q_lat__, snr__=snr__, resp_temp=resp_temp,
-                     respPair_temp=respPair_temp, reorder=reorder, gpmodels_temp=gpmodels_temp, plan=plan)
+                     respPair_temp=respPair_temp, reorder=reorder, gpmodels_temp=gpmodels_temp, plan=plan, Yp=Yp, lp=lp)
             props.append(P)
         # ... in two batches: the first candidate alone (it is the one most often accepted), then all the others.
         def rebuilds(ps):
-            return iter(self._passes(x, y, [(gp, ld, P["resp_temp"][:, m]) for P in ps for ld, m, r, gp, rebuild in P["plan"] if rebuild]))
+            return iter(self._passes(x, y, [(gp, self._ycol(P["Yp"], y, ld, r), P["resp_temp"][:, m])
+                                            for P in ps for ld, m, r, gp, rebuild in P["plan"] if rebuild]))
 
         outs = None
         for ip, P in enumerate(props):
@@ -588,12 +665,15 @@ class OfflineLoop:
             f_new, m_chosen, q_simple_, f_ind_old_temp = P["f_new"], P["m_chosen"], P["q_simple_"], P["f_ind_old_temp"]
             q, q_lat, snr_aux, q__, q_lat__, snr__ = P["q"], P["q_lat"], P["snr_aux"], P["q__"], P["q_lat__"], P["snr__"]
             resp_temp, respPair_temp, reorder, gpmodels_temp = P["resp_temp"], P["respPair_temp"], P["reorder"], P["gpmodels_temp"]
+            Yp, lp = P["Yp"], P["lp"]
             for ld, m, r, gp, rebuild in P["plan"]:
                 if rebuild:
                     out = next(outs)
                     self._note_full_pass(resp_temp[:, m], out)
                     q[:, m, ld], q_lat[:, m, ld] = out if out is not None else (q__[:, r, ld], q_lat__[:, r, ld])
-                    snr_aux[:, m, ld] = self.compute_snr(y[:, :, ld], gp)
+                    if lp is not None:
+                        q[:, m, ld] += lp[:, r, ld]
+                    snr_aux[:, m, ld] = self.compute_snr(self._ylead(Yp, y, ld, r), gp)
                 else:
                     q[:, m, ld] = q__[:, r, ld].clone()
                     q_lat[:, m, ld] = q_lat__[:, r, ld].clone()
@@ -612,8 +692,10 @@ class OfflineLoop:
                         gpmodels_temp[ld] = gpmodels_temp[ld][:-1]
                     resp_temp, respPair_temp, q, q_lat, snr_aux = self.remove_last_group(resp_temp, respPair_temp, q, q_lat, snr_aux)
                     self.gpmodels = gpmodels_temp
+                    for ld in range(D):
+                        self.wp_sys[ld] = self.wp_sys[ld][:-1]                    # quirk: only this exit drops a warper
                     self.f_ind_old = f_ind_old[reorder]
-                    self.y_train = y
+                    self.y_train = self.select_assigned_warp(Yp, y, resp_temp, reorder)
                     self.snr_norm = self.normalize_snr(snr_aux)
                     return resp_temp, respPair_temp, q, q_lat, snr_aux, True
                 self._log("Bad estimation")
@@ -632,7 +714,9 @@ class OfflineLoop:
                 if q_bas + elbo_bas < q_bas_post + elbo_post:
                     self._log(f"Chosen to divide: {m_chosen} with beat {f_new}")
                     self.gpmodels = gpmodels_temp
-                    self.y_train = y
+                    for ld in range(D):
+                        self.wp_sys[ld].append(self.create_wp_sys_default())
+                    self.y_train = self.select_assigned_warp(Yp, y, resp_temp, reorder)
                     self.f_ind_old = self._pick_representatives(resp_temp, self.weight_mean(q_simple_, snr_aux), M, f_ind_old)
                     self.snr_norm = self.normalize_snr(snr_aux)
                     return resp_temp, respPair_temp, q, q_lat, snr_aux, reallocate
@@ -692,11 +776,9 @@ class OfflineLoop:
         """GPI_HDP.py:805-943.  ``with_warp`` is what the reference's own drivers pass (hdpgpc/tests/test_offline.py:79)."""
         if with_warp is not None:
             warp = with_warp
-        if warp:
-            raise NotImplementedError("include_batch(warp=True): the warp fit inside the loop is not part of this build")
         if self.reduce_outputs:
             raise NotImplementedError("reduce_outputs is not part of this build")
-        self.warp = False
+        self.warp = bool(warp)
         self._log(f"------ HDP Hyperparameters ------\ngamma: {self.gamma}\ntransAlpha: {self.transAlpha}\n"
                   f"startAlpha: {self.startAlpha}\nkappa: {self.kappa}\n---------------------------------")
         y = self.cond_to_torch(y_trains)
@@ -798,7 +880,7 @@ class OfflineLoop:
         q = torch.zeros((N, self.M, D), dtype=f64, device=dev)
         q_lat, snr = torch.zeros_like(q), torch.zeros_like(q)
         models = [[self._fresh_copy(self.gpmodels[ld][int(reorder[m])]) for m in range(self.M)] for ld in range(D)]
-        outs = iter(self._passes(x, y, [(models[ld][m], ld, resp[:, m]) for ld in range(D) for m in range(self.M)]))
+        outs = iter(self._passes(x, y, [(models[ld][m], y[:, :, [ld]], resp[:, m]) for ld in range(D) for m in range(self.M)]))
         for ld in range(D):
             for m in range(self.M):
                 out = next(outs)

@@ -675,7 +675,7 @@ def _pack_trace(out, N, order, elbo, qall, fpw, em):
 
 
 # ------------------------------------- SURVEY 8b Face 1: the offline variational loop, GPI_HDP.include_batch
-def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5, leads=None):
+def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5, leads=None, warp=False):
     """Run the reference's include_batch exactly as hdpgpc/tests/test_offline.py:32-79 drives it (kernel fit replaced by the
     theta injection above) and record a TRACE of what the loop decided and computed: every ELBO evaluation
     (GPI_HDP.compute_q_elbo), every assignment returned by estimate_q_all, every full_pass_weighted, and per EM
@@ -692,9 +692,9 @@ def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5, leads=None):
                      bound_noise_warp=(std * 0.01, std * 0.02), warp_updating=False, method_compute_warp="greedy",
                      verbose=False, hmm_switch=True, max_models=100, mode_warp="rough", bayesian_params=True,
                      inducing_points=False, reestimate_initial_params=True, n_explore_steps=n_explore, free_deg_MNIV=5)
-    order, elbo, qall, fpw, em, wall, _ = _trace_loop(sw, lambda: sw.include_batch(x_trains, data, warp=False))
+    order, elbo, qall, fpw, em, wall, _ = _trace_loop(sw, lambda: sw.include_batch(x_trains, data, warp=warp))
     out = {"y": data[..., 0] if D == 1 else data, "x_basis": xb[:, 0], "estimators": np.array([std, std_dif, *bound_sigma, *bound_gamma]),
-           "theta_inject": np.array(THETA_INJECT), "n_explore": np.array(n_explore), "wall_s": np.array(wall),
+           "theta_inject": np.array(THETA_INJECT), "n_explore": np.array(n_explore), "wall_s": np.array(wall), "warp": np.array(warp),
            "M_final": np.array(sw.M), "train_elbo": np.array([float(e) for e in sw.train_elbo]),
            "resp_assigned": np.stack([npy(r).astype(np.int16) for r in sw.resp_assigned]),
            "f_ind_old": npy(sw.f_ind_old).astype(np.int64), "transTheta": npy(sw.transTheta), "startTheta": npy(sw.startTheta),
@@ -850,6 +850,8 @@ if __name__ == "__main__":
         gen_producer_extra()
     if "ib80" in which:
         gen_include_batch("r100_n80", "100", 80)
+    if "ibw" in which:
+        gen_include_batch("r100_n80_warp", "100", 80, warp=True)
     if "ib2" in which:
         gen_include_batch("r102_2leads_n100", "102", 100, leads=(0, 1), n_explore=5)
     if "ib100" in which:

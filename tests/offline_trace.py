@@ -71,9 +71,9 @@ def traced(sw, run):
     return tr
 
 
-def run_traced(g, y, it_limit=None):
+def run_traced(g, y, it_limit=None, warp=False):
     sw, x_trains, data = build_model(g, y)
-    return sw, traced(sw, lambda: sw.include_batch(x_trains, data, with_warp=False, it_limit=it_limit))   # the drivers' keyword
+    return sw, traced(sw, lambda: sw.include_batch(x_trains, data, with_warp=warp, it_limit=it_limit))   # the drivers' keyword
 
 
 def run_cluster_learning(g):
