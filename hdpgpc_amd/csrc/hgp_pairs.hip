@@ -29,10 +29,12 @@ namespace {
 
 // PAIRS_CUT (block-wise cut-off of E and K**): hgp_internal.hpp
 
+constexpr int PAIRS_DCOLS = 16;   // clusters whose d = y - E^T a' one pass of the workgroup prepares (one MFMA column block)
+
 template <int NB>
 constexpr size_t pairs_lds_bytes() {
-  return sizeof(double) * ((size_t)(16 * NB) * (16 * NB) + 3 * 16 * NB + WAVES * DIAG_SCR + WAVES * 16 * NB) +
-         sizeof(int) * 16;
+  return sizeof(double) * ((size_t)(16 * NB) * (16 * NB) + 3 * 16 * NB + WAVES * DIAG_SCR + PAIRS_DCOLS * 16 * NB) +
+         sizeof(int) * 32;
 }
 
 // One workgroup per segment n; its 4 waves take the clusters of the length-scale group round-robin.
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   double* xbs = ys + TP;          // basis grid / ell
   const int tid = threadIdx.x, wave = tid >> 6;
   double* scr = xbs + TP + wave * DIAG_SCR;
-  double* dv = xbs + TP + WAVES * DIAG_SCR + wave * TP;
-  int* amask = reinterpret_cast<int*>(xbs + TP + WAVES * DIAG_SCR + WAVES * TP);   // bit Kt of amask[J]: block (Kt, J) of E active
+  double* dall = xbs + TP + WAVES * DIAG_SCR;   // [PAIRS_DCOLS][TP]: d = y - E^T a' of the clusters of the current chunk, then z = L^{-1} d
+  int* amask = reinterpret_cast<int*>(dall + PAIRS_DCOLS * TP);   // bit Kt of amask[J]: block (Kt, J) of E active
   const int n = blockIdx.x;
   const int T = a.T, Ts = a.Ts;
 
@@ -100,8 +102,67 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   }
   __syncthreads();
 
+  // K** = c exp(-0.5 (x_i - x_j)^2 / ell^2) depends on the segment only: its active tiles (without the factor c) are built ONCE
+  // per workgroup and kept in blocks of the E array that E itself does not use - tile (I, J) in block ((I + NB/2) % NB, J) -
+  // instead of 4 exp per lane and tile in every pair (16 k of a pair's 246 k cycles at T = 128).  Decided from the
+  // data: if any home block is an active block of E (dense grids, NB < 6) the pairs compute the tiles themselves as before.
+  bool kcache = (NB >= 6);
+#pragma unroll
+  for (int J = 0; J < NB; ++J) {
+    const int km = kmask[J], rot = ((km << NH) | (km >> (NB - NH))) & ((1 << NB) - 1);
+    kcache = kcache && ((rot & amask[J]) == 0);
+  }
+  kcache = __builtin_amdgcn_readfirstlane((int)kcache) != 0;
+  if (kcache) {
+    const int lane = tid & 63, g = lane >> 4, c = lane & 15;
+    for (int t = wave; t < NB * NB; t += WAVES) {
+      const int I = t / NB, J = t % NB;
+      if (I > J || !((kmask[J] >> I) & 1)) continue;
+      const int Kh = (I + NH) % NB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double u = xs[16 * I + g + 4 * r] - xs[16 * J + c];
+        E[(16 * Kh + g + 4 * r) * TP + 16 * J + c] = HGP_EXPF(-0.5 * (u * u));
+      }
+    }
+  }
+
   HGP_STAMP_DECL
-  for (int kk = a.kbeg + wave; kk < a.kend; kk += WAVES) {
+  const int Kg = a.kend - a.kbeg;
+  for (int ch = 0; ch < Kg; ch += PAIRS_DCOLS) {
+  // d = y - E^T a'  (a' = c K~^{-1} mean) for the clusters ch .. ch + 15 of the group at once, on the matrix core: column c of
+  // the B operand is cluster c's a', the A operand is the transposed block of E - one MFMA chain per block column of E,
+  // shared by all the workgroup's pairs (was: 8 LDS-fed dot products per pair, 10 k cycles each).
+  if (ch) __syncthreads();
+  {
+    HGP_T0();
+    const int lane = launder(tid) & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const bool col = ch + c < Kg;
+    const double* apc = a.ap + (size_t)(col ? a.perm[a.kbeg + ch + c] : 0) * TP + g;
+    for (int Jb = wave; Jb < NB; Jb += WAVES) {
+      const int mJ = __builtin_amdgcn_readfirstlane(amask[Jb]);
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int Kt = 0; Kt < NB; ++Kt) {
+        if (mJ & (1 << Kt)) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double bv = apc[16 * Kt + 4 * s];
+            acc = mfma(E[(16 * Kt + 4 * s + g) * TP + 16 * Jb + c], col ? bv : 0.0, acc);
+          }
+        }
+      }
+      if (col) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dall[c * TP + 16 * Jb + g + 4 * r] = ys[16 * Jb + g + 4 * r] - acc[r];   // padded entries: 0 - 0
+      }
+    }
+    HGP_ACC(0);
+  }
+  __syncthreads();
+  const int kk_end = (a.kbeg + ch + PAIRS_DCOLS < a.kend) ? a.kbeg + ch + PAIRS_DCOLS : a.kend;
+  for (int kk = a.kbeg + ch + wave; kk < kk_end; kk += WAVES) {
     const int lane = launder(tid) & 63;
     const int g = lane >> 4, c = lane & 15;
     const int kc = a.perm[kk];
@@ -119,37 +180,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
       msk[J] = __builtin_amdgcn_readfirstlane(amask[J]);
       kmsk[J] = __builtin_amdgcn_readfirstlane(kmask[J]);
     }
-
-    // d = y - E^T a'   (a' = c K~^{-1} mean), column block by column block over the active blocks of E
-    const double* apk = a.ap + (size_t)kc * TP;
-    double apr[NB][4];   // a'[16 Kt + g + 4 r]: one batch of L2 loads per pair instead of one per block
-#pragma unroll
-    for (int Kt = 0; Kt < NB; ++Kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) apr[Kt][r] = apk[16 * Kt + g + 4 * r];
-    double dsq = 0.0;
-#pragma unroll
-    for (int Jb = 0; Jb < NB; ++Jb) {
-      double p = 0.0;
-#pragma unroll
-      for (int Kt = 0; Kt < NB; ++Kt) {
-        if (msk[Jb] & (1 << Kt)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) p = fma(E[(16 * Kt + g + 4 * r) * TP + 16 * Jb + c], apr[Kt][r], p);
-        }
-      }
-      p = xrow_sum(p);
-      if (g == 0) {
-        const int j = 16 * Jb + c;
-        const double d = ys[j] - p;     // padded entries: 0 - 0
-        dv[j] = d;
-        dsq = fma(d, d, dsq);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    HGP_ACC(0);
+    double* dv = dall + (kk - a.kbeg - ch) * TP;
 
     if (iso) {   // GPI.py:497-498: cov_f = mean(diag Sigma) I
+      double dsq = 0.0;
+#pragma unroll
+      for (int i = 0; i < TP; i += 64) {
+        const double d = (i + lane < TP) ? dv[(i + lane < TP) ? i + lane : 0] : 0.0;
+        dsq = fma(d, d, dsq);
+      }
       double v = sc[4] + fn;
       double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
       double q = wave_sum(dsq) / v2;
@@ -282,10 +321,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
             const int ln = launder(lane);
             d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
             if (kmsk[J] & (1 << I)) {
+              if (kcache) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
-                kt[r] = cc * HGP_EXPF(-0.5 * (u * u));
+                for (int r = 0; r < 4; ++r) kt[r] = cc * E[(16 * ((I + NH) % NB) + (ln >> 4) + 4 * r) * TP + 16 * J + (ln & 15)];
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
+                  kt[r] = cc * HGP_EXPF(-0.5 * (u * u));
+                }
               }
             }
             if (I == J) {   // exact diagonal of the one-argument kernel call; identity on the padding
@@ -352,6 +396,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     hgp_acc_[7] += pa.diag_cycles;
 #endif
   }
+  }   // chunks of PAIRS_DCOLS clusters
 #ifdef HGP_STAMPS
   if ((tid & 63) == 0 && a.stamps)
     for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);

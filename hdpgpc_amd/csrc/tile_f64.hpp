@@ -338,6 +338,145 @@ __device__ __forceinline__ d4 diag16_valu(const d4& X, double* scr, int lane, Pi
   return w;
 }
 
+// 1/a (a != 0, normal range): v_rcp_f64 seed + ONE third-order step  y (1 + e + e^2),  e = 1 - a y  (seed error < 2^-22 ->
+// < 2^-66), three dependent operations after the seed instead of the four of two Newton steps.
+__device__ __forceinline__ double rcp_nr(double a) {
+  const double y = __builtin_amdgcn_rcp(a);
+  const double e = fma(-a, y, 1.0);
+  const double ye = y * e;
+  return fma(ye, e, y + ye);
+}
+
+// product over the 16 lanes of each row of the wave (every lane gets its row's result); DPP rotations only
+__device__ __forceinline__ double row16_prod(double v) {
+  v *= dpp_f64<0x128>(v);   // row_ror:8
+  v *= dpp_f64<0x124>(v);   // row_ror:4
+  v *= dpp_f64<0x122>(v);   // row_ror:2
+  v *= dpp_f64<0x121>(v);   // row_ror:1
+  return v;
+}
+__device__ __forceinline__ int row16_sum_i32(int v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);
+  v += __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, false);
+  v += __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, false);
+  v += __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, false);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// diag16_col (round 3): the column form of diag16_valu with a third of its instructions.  Measured first (tools/probe_lat.hip,
+// profiles/r03_probe_lat.txt): a dependent v_fma_f64 issues 9.5 cycles after its producer, v_rsq/v_rcp_f64 21, a v_readlane pair
+// feeding an FMA ~10, an LDS write -> read round trip 77; independent f64 VALU instructions issue every ~5 cycles.  The 4.2 k
+// cycles of diag16_valu are therefore its ~950 INSTRUCTIONS (two v_readlane_b32 per multiplier, a 7-instruction 1/sqrt, pivot
+// bookkeeping in every step), not its dependency chain (~100 cycles per pivot).  Here:
+//   * the rows stay UNSCALED Schur-complement rows S[k][.] during the elimination: step k publishes row k in LDS (one ds_write),
+//     multiplies the pivot row by 1/pivot (v_rcp + one third-order step: t = S[k][.] / p_k) and updates v[k'] -= S[k][k'] t with
+//     the multipliers S[k][k'] read back as LDS BROADCASTS (one ds_read2_b64 per two rows; only the multiplier of row k + 1,
+//     which carries the next pivot, comes through v_readlane so that the LDS round trip stays off the pivot chain);
+//   * the sixteen 1/sqrt(p_k) are ONE rsqrt sequence after the loop (lane c takes p_c = S[c][c] from the published rows), the row
+//     scaling of Z = L^{-1} happens in the final transposition (row c of W is lane-local), and the pivot product / the first bad
+//     pivot are one DPP reduction and one ballot instead of sixteen multiply / compare / renormalise groups.
+// Same interface and the same results up to rounding (the multipliers are S/p instead of (S/sqrt p)(S/sqrt p)).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ d4 diag16_col(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
+                                         double* Lout, int ldl, int nvalid) {
+  const int g = lane >> 4, c = lane & 15;
+#ifdef HGP_EXP_NODIAG   // in-situ knock-out experiment (diagnostic builds only)
+  {
+    d4 w;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = (4 * s + g == c) ? 1.0 / sqrt(fabs(X[s]) + 1.0) : 0.0;
+    pa.mant *= 1.0 + 1e-300 * X[0];
+    return w;
+  }
+#endif
+#ifdef HGP_STAMPS
+  const unsigned long long td0 = __builtin_readcyclecounter();
+#endif
+  const bool zrole = (g & 1) != 0;   // lanes 16-31: column c of Z (starts as I); lanes 0-15: column c of X; 32-63 mirror 0-31
+#pragma unroll
+  for (int r = 0; r < 4; ++r) scr[(g + 4 * r) * DIAG_LD + c] = X[r];
+  if (lane < 16) scr[lane * DIAG_LD + 16] = 0.0;           // padding column 16 of the staging tile: what the Z lanes load
+  __builtin_amdgcn_wave_barrier();
+  double v[16];
+  {
+    const int cz = zrole ? 16 : c;                         // Z lanes read zeros, then get their 1.0 (one compare + one select per row)
+    const int ci = zrole ? c : -1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const double x = scr[i * DIAG_LD + cz];              // X[i][c]: column c (the upper part is what matters)
+      v[i] = __hiloint2double((ci == i) ? 0x3FF00000 : __double2hiint(x), __double2loint(x));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // the staging tile is dead: row k of the multipliers goes to scr[16 k ..] (LDS operations of one wave complete in order)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (!zrole) scr[16 * k + c] = v[k];                    // S[k][c], unscaled
+    __builtin_amdgcn_wave_barrier();
+    const double piv = lane_bcast(v[k], k);
+    const double t = v[k] * rcp_nr(piv);
+    if (k + 1 < 16) {
+      const double m1 = lane_bcast(v[k], k + 1);           // the next pivot's row first, without the LDS round trip
+      v[k + 1] = fma(-m1, t, v[k + 1]);
+    }
+#pragma unroll
+    for (int kp = k + 2; kp < 16; ++kp) v[kp] = fma(-scr[16 * k + kp], t, v[kp]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const double pv = scr[16 * c + c];                       // p_c = S[c][c]
+  const double rc = rsqrt_nr(pv);                          // NaN for a pivot <= 0 (or NaN): poisons row c of W, info says where
+  {
+    const unsigned long long bad = __ballot(!(pv > 0.0)) & 0xffffull;
+    if (bad != 0 && pa.info == 0) pa.info = col0 + __ffsll((long long)bad);
+    pa.mant *= row16_prod(__builtin_amdgcn_frexp_mant(pv));      // sixteen mantissas in [0.5, 1): no underflow
+    pa.ex += row16_sum_i32(__builtin_amdgcn_frexp_exp(pv));
+    pa.renorm();
+  }
+  if (Lout != nullptr) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) scr[256 + lane] = rc;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16 && lane < nvalid) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < nvalid) Lout[(size_t)lane * ldl + i] = (i <= lane) ? v[i] * scr[256 + i] : 0.0;   // L[j][i] = U[i][j] = r_i S[i][j]
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane >= 16 && lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) scr[i * DIAG_LD + c] = v[i];                       // unscaled Z rows: Zs[i][j], j = c
+  }
+  __builtin_amdgcn_wave_barrier();
+  d4 w;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) w[s] = scr[c * DIAG_LD + 4 * s + g] * rc;             // W[c][4s+g] = r_c Zs[c][4s+g]
+  __builtin_amdgcn_wave_barrier();
+#ifdef HGP_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  pa.diag_cycles += __builtin_readcyclecounter() - td0;
+#endif
+  return w;
+}
+
+// Which 16 x 16 diagonal-block routine the factorisations use (A/B builds: -DHGP_DIAG_IMPL=0 restores rounds 1-2:
+// diag16_valu where the register budget asks for it, the MFMA-blocked diag16 elsewhere).
+#ifndef HGP_DIAG_IMPL
+#define HGP_DIAG_IMPL 0   // 1 = diag16_col instead of diag16_valu only; 2 = diag16_col everywhere (both measured SLOWER in the kernels: see diag16_col)
+#endif
+template <bool VALU>
+__device__ __forceinline__ d4 diag16_sel(const d4& X, double* scr, int lane, PivotAcc& pa, int col0, double* Lout, int ldl,
+                                         int nvalid) {
+#if HGP_DIAG_IMPL == 2
+  return diag16_col(X, scr, lane, pa, col0, Lout, ldl, nvalid);
+#elif HGP_DIAG_IMPL == 1
+  return VALU ? diag16_col(X, scr, lane, pa, col0, Lout, ldl, nvalid) : diag16(X, scr, lane, pa, col0, Lout, ldl, nvalid);
+#else
+  return VALU ? diag16_valu(X, scr, lane, pa, col0, Lout, ldl, nvalid) : diag16(X, scr, lane, pa, col0, Lout, ldl, nvalid);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Upper-form blocked Cholesky of an NB x NB tile matrix held in registers (upper tiles only),
 // right-looking, with ONE block column of 16 right-hand sides eliminated in the same sweep:
@@ -359,8 +498,7 @@ __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;
     double* Ld = (Lout != nullptr) ? Lout + (size_t)(16 * K) * ldl + 16 * K : nullptr;
-    const d4 W = DIAG_VALU ? diag16_valu(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K)
-                           : diag16(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
+    const d4 W = diag16_sel<DIAG_VALU>(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
     if (Wlds != nullptr) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) Wlds[(K * 4 + s) * 64 + lane] = W[s];
@@ -779,7 +917,7 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
     const int g = lane >> 4, c = lane & 15;
     if (wave == wK) {
       double* Ld = (Lout != nullptr) ? Lout + (size_t)(16 * K) * ldl + 16 * K : nullptr;
-      const d4 Wd = diag16(U[C::loc(K, qK)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
+      const d4 Wd = diag16_sel<false>(U[C::loc(K, qK)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
 #pragma unroll
       for (int s = 0; s < 4; ++s) Wbuf[s * 64 + lane] = Wd[s];
       if (Wout != nullptr) {
@@ -1001,7 +1139,7 @@ __device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* r
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;
     if (wave == C::owner(K)) {
-      const d4 Wd = diag16(U[C::diag_slot(K)], scr, lane, pa, 16 * K, nullptr, 0, n - 16 * K);
+      const d4 Wd = diag16_sel<false>(U[C::diag_slot(K)], scr, lane, pa, 16 * K, nullptr, 0, n - 16 * K);
 #pragma unroll
       for (int s = 0; s < 4; ++s) Wbuf[s * 64 + lane] = Wd[s];
       double p = 0.0;   // z_K = W d_K
@@ -1168,7 +1306,7 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
     const int g = lane >> 4, c = lane & 15;
     HGP_DF(4);
     __builtin_amdgcn_s_setprio(3);
-    const d4 Wd = diag16(U[C::diag_slot(K)], scr, lane, pa, 16 * K, nullptr, 0, n - 16 * K);
+    const d4 Wd = diag16_sel<false>(U[C::diag_slot(K)], scr, lane, pa, 16 * K, nullptr, 0, n - 16 * K);
 #pragma unroll
     for (int s = 0; s < 4; ++s) Wall[(K * 4 + s) * 64 + lane] = Wd[s];
     double p = 0.0;   // z_K = W d_K

@@ -133,10 +133,9 @@ def test_frozen_scores_mixed_grids_match_per_segment_calls():
 
 
 def test_unbuilt_options_say_so():
-    """What this build does not cover raises instead of silently doing something else: warping inside the loops."""
+    """What this build does not cover raises instead of silently doing something else: the per-beat warp of the online step
+    (include_batch(with_warp=True) is built: tests/test_gpu_include_batch.py::test_include_batch_warp_first80)."""
     g = golden("reload_r102.npz")
     sw_gp, x_trains, data = _driver(g)
-    with pytest.raises(NotImplementedError):
-        sw_gp.include_batch(x_trains[:4], data[:4], with_warp=True)
     with pytest.raises(NotImplementedError):
         sw_gp.include_sample(x_trains[0], data[0], with_warp=True)

@@ -25,12 +25,12 @@ def test_include_batch_r100_first80():
 def test_include_batch_warp_first80():
     """include_batch(warp=True) (GPI_HDP.py:3412-3525 inside the loop): every segment is warped onto the representative of every
     cluster column by the batched Adam fit (hgp_warp_batch_f64) before it is scored.  The reference fits the same warps with
-    torch.optim.Adam one segment at a time; the fitted warps agree to 1e-6 (tests/test_gpu_warp_batch.py), so the scores computed
-    from them carry that tolerance; the decisions must still be identical."""
+    torch.optim.Adam one segment at a time (fitted warps agree to 1e-6, tests/test_gpu_warp_batch.py); observed on the scores: 1.8e-9;
+    the decisions must be identical."""
     g = golden("include_batch_r100_n80_warp.npz")
     assert bool(g["warp"])
     sw, tr = run_traced(g, g["y"], warp=True)
-    worst = compare_trace(g, sw, tr, q_tol=1e-5)
+    worst = compare_trace(g, sw, tr, q_tol=1e-7)
     print(f"include_batch(warp=True), 80 beats: {len(tr['order'])} traced calls, worst relative error {worst:.2e}")
 
 
