@@ -101,6 +101,7 @@ struct PairsArgs {
   int32_t* eflags;       // [nscr] 0 = free
   int nscr;
   long escr_stride;
+  int flags;             // bit 0: generic (mask-driven) sweeps even for a block-tridiagonal E (HGP_PAIRS_GENERIC=1: A/B runs and tests)
 };
 
 #ifdef HGP_STAMPS

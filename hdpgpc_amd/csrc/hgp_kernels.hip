@@ -1802,7 +1802,8 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
 #ifdef HGP_STAMPS
                 hgp_internal_stamp_dev,
 #endif
-                p->K, out_quad, out_logdet, out_info, p->d_escr, p->d_eflags, p->nscr, p->escr_stride};
+                p->K, out_quad, out_logdet, out_info, p->d_escr, p->d_eflags, p->nscr, p->escr_stride,
+                env_on("HGP_PAIRS_GENERIC") ? 1 : 0};
     rc = hgp_internal_pairs_fast(a, p->NB, p->coop, st);
   }
   if (rc == 0) rc = hgp_internal_pairs_acc(p, x, y, N, Ts, first_noise, sel, out_quad, out_logdet, out_info, st);

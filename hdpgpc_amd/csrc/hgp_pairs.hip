@@ -37,6 +37,145 @@ constexpr size_t pairs_lds_bytes() {
          sizeof(int) * 32;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The two sweeps of k_pairs for the BLOCK-TRIDIAGONAL E of the reference's setting (length-scale 1.2 on a unit-spaced grid, any
+// jitter below the cut-off radius: blocks |Kt - J| <= 1 of E and tiles J - 1 <= I <= J of K** active, nothing else), as
+// straight-line code.  The workgroup checks its masks against this pattern (from the data, as ever) and takes the generic
+// mask-driven sweeps below for anything else.  What the static schedule buys (round 3):
+//  * sweep 1 computes only the row tiles of B_J = (M'E)[:, J] that sweep 2 reads (Kt <= J + 1): 476 instead of 704 MFMAs per pair
+//    at NB = 8 - the generic code can only drop whole halves, predicating single row tiles costs more in branches than it saves;
+//  * no bit scans, no scalar branches, no conditional refills around the operand ring: one flat list of (column, half, k-block,
+//    half-block) items, item t multiplied from ring slot t % 4 and the slot refilled with item t + 4 (exact s_waitcnt counts);
+//  * the K** seeds and sweep 2 of a pass follow its last item with compile-time tile lists.
+// Same operations in the same order per accumulator as the generic sweeps: bit-identical results (HGP_PAIRS_GENERIC=1 runs the
+// generic code for A/B; tests/test_gpu_edge_cases.py compares the two).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NB>
+struct PairsBand {
+  static constexpr int NH = NB / 2;
+  static constexpr int lo(int J) { return J > 0 ? J - 1 : 0; }
+  static constexpr int hi(int J) { return J + 1 < NB ? J + 1 : NB - 1; }
+  static constexpr int emask(int J) { return ((1 << (hi(J) + 1)) - 1) & ~((1 << lo(J)) - 1); }   // blocks (Kt, J) of E
+  static constexpr int kmask(int J) { return ((1 << (J + 1)) - 1) & ~((1 << lo(J)) - 1); }        // tiles (I, J) of K**
+  static constexpr int rows(int J, int h) {   // row tiles NH h + i of B[:, J] that sweep 2 reads: NH h + i <= J + 1
+    int m = 0;
+    for (int i = 0; i < NH; ++i)
+      if (NH * h + i <= hi(J)) m |= 1 << i;
+    return m;
+  }
+  struct Item {
+    int J, h, Lt, hb, first, last, valid;
+  };
+  static constexpr Item item(int t) {
+    int cnt = 0;
+    for (int J = 0; J < NB; ++J)
+      for (int h = 0; h < 2; ++h) {
+        if (!rows(J, h)) continue;
+        for (int Lt = lo(J); Lt <= hi(J); ++Lt)
+          for (int hb = 0; hb < 2; ++hb) {
+            if (cnt == t) return Item{J, h, Lt, hb, Lt == lo(J) && hb == 0, Lt == hi(J) && hb == 1, 1};
+            ++cnt;
+          }
+      }
+    return Item{0, 0, 0, 0, 0, 0, 0};
+  }
+  static constexpr int nitems() {
+    int cnt = 0;
+    for (int J = 0; J < NB; ++J)
+      for (int h = 0; h < 2; ++h)
+        if (rows(J, h)) cnt += 2 * (hi(J) - lo(J) + 1);
+    return cnt;
+  }
+};
+
+template <int NB>
+__device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const double* __restrict__ Mbase, const double* E,
+                                            int lane_in, double cc, double noise, int Ts) {
+  using PB = PairsBand<NB>;
+  constexpr int TP = 16 * NB, NH = NB / 2, NI = PB::nitems();
+  double ra[4][2][NH], re[4][2];
+  d4 BJ[NH];
+  auto fill = [&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr auto it = PB::item(t);
+    if constexpr (it.valid) {
+      constexpr int slot = t & 3, rm = PB::rows(it.J, it.h);
+      const int lane = launder(lane_in);
+      const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const double* row_ = Mbase + 16 * NH * it.h + (size_t)(16 * it.Lt + 4 * (2 * it.hb + s_)) * TP;
+#pragma unroll
+        for (int P_ = 0; P_ < NH / 2; ++P_) {
+          if ((rm >> (2 * P_)) & 3) {
+            const d2 t_ = *reinterpret_cast<const d2*>(row_ + 32 * P_ + 2 * c);
+            ra[slot][s_][2 * P_] = t_[0];
+            ra[slot][s_][2 * P_ + 1] = t_[1];
+          }
+        }
+        if ((NH & 1) && ((rm >> (NH - 1)) & 1)) ra[slot][s_][NH - 1] = row_[16 * (NH - 1) + c];
+        re[slot][s_] = E[(16 * it.Lt + 4 * (2 * it.hb + s_) + g) * TP + 16 * it.J + c];
+      }
+    }
+  };
+  fill(std::integral_constant<int, 0>{});
+  fill(std::integral_constant<int, 1>{});
+  fill(std::integral_constant<int, 2>{});
+  fill(std::integral_constant<int, 3>{});
+  static_for<0, NI>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr auto it = PB::item(t);
+    constexpr int slot = t & 3, rm = PB::rows(it.J, it.h), J = it.J, h = it.h;
+    if constexpr (it.first) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i) BJ[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i)
+        if ((rm >> i) & 1) BJ[i] = mfma(ra[slot][s_][i], re[slot][s_], BJ[i]);
+    }
+    fill(std::integral_constant<int, t + 4>{});
+    if constexpr (it.last) {
+      const int ln = launder(lane_in);
+      const int g = ln >> 4, c = ln & 15;
+      if constexpr (h == 0) {   // K** seeds of column J (cached tiles, see k_pairs) + the exact diagonal
+#pragma unroll
+        for (int I = 0; I <= J; ++I) {
+          d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
+          if ((PB::kmask(J) >> I) & 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kt[r] = cc * E[(16 * ((I + NH) % NB) + g + 4 * r) * TP + 16 * J + c];
+          }
+          if (I == J) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (g + 4 * r == c) kt[r] = (16 * I + c < Ts) ? cc + noise : 1.0;
+          }
+          cov[tix(I, J, NB)] = kt;
+        }
+      }
+      // sweep 2: cov[I][J] += E[Kt, I]^T BJ[Kt] over the blocks |Kt - I| <= 1, I <= J
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        if ((rm >> i) & 1) {
+#pragma unroll
+          for (int I = 0; I <= J; ++I) {
+            if ((PB::emask(I) >> (NH * h + i)) & 1) {
+              double af[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) af[r] = E[(16 * (NH * h + i) + 4 * r + g) * TP + 16 * I + c];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) cov[tix(I, J, NB)] = mfma(af[r], BJ[i][r], cov[tix(I, J, NB)]);
+            }
+          }
+        }
+      }
+    }
+  });
+}
+
 // One workgroup per segment n; its 4 waves take the clusters of the length-scale group round-robin.
 // E_n = exp(-0.5 ((xb_k - x_j)/ell)^2) is built once per workgroup in LDS (active 16x16 blocks only) and shared by
 // the waves; each wave then evaluates one (segment, cluster) pair entirely in its own registers:
@@ -113,6 +252,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     kcache = kcache && ((rot & amask[J]) == 0);
   }
   kcache = __builtin_amdgcn_readfirstlane((int)kcache) != 0;
+  // block-tridiagonal E and K** (the reference's setting): the static sweeps (band_sweeps) instead of the mask-driven ones
+  bool band = (NB >= 6) && kcache && !(a.flags & 1);
+#pragma unroll
+  for (int J = 0; J < NB; ++J) band = band && amask[J] == PairsBand<NB>::emask(J) && kmask[J] == PairsBand<NB>::kmask(J);
+  band = __builtin_amdgcn_readfirstlane((int)band) != 0;
   if (kcache) {
     const int lane = tid & 63, g = lane >> 4, c = lane & 15;
     for (int t = wave; t < NB * NB; t += WAVES) {
@@ -210,6 +354,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #else
     const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP;   // + column offset inside HGP_FILL (interleaved)
 #endif
+    if (band) {
+      band_sweeps<NB>(cov, Mbase, E, lane, cc, noise, Ts);
+    } else {
     // Sweep-1 operand ring: 4 slots of half a k-block each (2 k-steps: 2 x NH rows of M' from L2 + 2 values of E
     // from LDS).  A slot is refilled right after its MFMAs are issued, i.e. three half-blocks (about 1.5k cycles
     // of MFMA) before it is used again; the first two blocks of the NEXT sweep are requested at the end of a sweep.
@@ -365,6 +512,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
         HGP_ACC(3);
       }
     }
+    }   // generic (mask-driven) sweeps
 
     // regularisation of the reference: +1e-6 I (GPI.py:501), + first, + 1e-8 mean|diag| I (GPI_model.py:83-87)
     {

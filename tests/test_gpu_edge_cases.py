@@ -255,3 +255,32 @@ def test_assignment_tail_treats_nan_like_torch():
     b = torch.ones_like(f)
     labels = ops.assign(f.contiguous(), b.contiguous()).cpu()
     assert torch.equal(labels, torch.argmax(torch.log(f.cpu() * b.cpu()), dim=1))
+
+
+@pytest.mark.parametrize("T, Ts", [(128, 128), (90, 90), (120, 128), (128, 100), (96, 96)])
+def test_static_band_sweeps_equal_the_mask_driven_ones_bit_for_bit(T, Ts, monkeypatch):
+    """k_pairs takes straight-line sweeps when the workgroup's E is block-tridiagonal (band_sweeps, hgp_pairs.hip) and the
+    mask-driven ones otherwise: same operations in the same order per accumulator, so the two must agree to the last bit -
+    on jittered unit grids (band everywhere), and on a batch where some segments are NOT banded (stretched / reversed grids take
+    the generic path inside the same launch).  HGP_PAIRS_GENERIC=1 forces the generic sweeps."""
+    N, K = 96, 5
+    b = orc.synthetic_batch(N, K, T, seed=7 + T + Ts)
+    rng = np.random.default_rng(Ts)
+    x = np.arange(Ts, dtype=np.float64)[None, :] * (T - 1.0) / max(Ts - 1.0, 1.0) + rng.uniform(-0.3, 0.3, size=(N, Ts))
+    x[5] = x[5][::-1].copy()                       # reversed grid: anti-diagonal E
+    x[11] = 0.5 * x[11]                            # compressed grid: wider band
+    y = rng.normal(0.0, 30.0, size=(N, Ts))
+    plan = ops.PairsPlan(T, Ts, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    fn = dev(rng.uniform(0.0, 2.0, size=(N, K)))
+    monkeypatch.delenv("HGP_PAIRS_GENERIC", raising=False)
+    q1, l1, i1 = plan.loglik(dev(x), dev(y), first_noise=fn)
+    monkeypatch.setenv("HGP_PAIRS_GENERIC", "1")
+    q0, l0, i0 = plan.loglik(dev(x), dev(y), first_noise=fn)
+    monkeypatch.delenv("HGP_PAIRS_GENERIC", raising=False)
+    assert int(i0.abs().max()) == 0 and int(i1.abs().max()) == 0
+    assert torch.equal(q0, q1) and torch.equal(l0, l1)
+    # and both against the oracle on a few pairs
+    for n in (0, 5, 11, N - 1):
+        for k in (0, K - 1):
+            _, qq, ll = orc.log_sq_error_state(x[n], y[n], b["xb"], b["mean"][k], b["Sigma"][k], tuple(b["theta"][k]), float(fn[n, k]))
+            assert abs(float(q1[n, k]) - qq) <= 1e-8 * abs(qq) and abs(float(l1[n, k]) - ll) <= 1e-8 * abs(ll)
