@@ -32,6 +32,8 @@ static inline bool env_on(const char* name) {
 // the blocks |Kt - J| <= 1 survive, which removes ~60 % of the MFMA work at T = 128.  The decision is taken from the
 // data (any grid), never from an assumed band structure.
 constexpr double PAIRS_CUT = 82.9;
+// segments per launch pair of k_pairs<NB, true> / k_pairs<NB, false> (capacity of the fall-back list of the plan)
+constexpr int PAIRS_FB_CAP = 65536;
 
 // number of workgroups (and S scratch areas) of the solve-based pairs kernel (hgp_pairs_acc.hip)
 static inline int acc_grid_for(int nb) { return nb > 8 ? 256 : 512; }
@@ -60,6 +62,7 @@ struct hgp_pairs_plan {
   double* d_mu = nullptr;       // [K][TP] prior means on the basis grid (zero padded)
   int32_t* d_acc_list = nullptr;   // [1 + K]: number of flagged clusters, then their ids
   double* d_sscr = nullptr;     // [acc_grid][NB*NB][64][4]: per-workgroup storage of S = K~^{-1} K*
+  int32_t* d_fb = nullptr;      // [PAIRS_FB_CAP + 2]: fall-back list of k_pairs (see PairsArgs::fb); zero between launches
 };
 
 // hgp_pairs_acc.hip
@@ -102,6 +105,7 @@ struct PairsArgs {
   int nscr;
   long escr_stride;
   int flags;             // bit 0: generic (mask-driven) sweeps even for a block-tridiagonal E (HGP_PAIRS_GENERIC=1: A/B runs and tests)
+  int32_t* fb;           // k_pairs: fall-back list [0] = count, [1 .. PAIRS_FB_CAP] = segments, [1 + PAIRS_FB_CAP] = finished workgroups
 };
 
 #ifdef HGP_STAMPS

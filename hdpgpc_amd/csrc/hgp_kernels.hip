@@ -1467,10 +1467,15 @@ struct PrepFinalArgs {
   double* Mp;           // [K,TP,TP]
   double* ap;           // [K,TP]
   int interleave;       // 1: tile-pair interleaved columns (fused pairs kernel); 0: plain row-major (cooperative pairs kernel)
+  int32_t* fb;          // fall-back list of k_pairs: its two counters start every plan state at zero (a killed launch cannot leave them set)
 };
 
 __global__ __launch_bounds__(256) void k_prep_final(PrepFinalArgs a) {
   const int k = blockIdx.x, tid = threadIdx.x;
+  if (a.fb && k == 0 && blockIdx.y == 0 && tid == 0) {
+    a.fb[0] = 0;
+    a.fb[1 + PAIRS_FB_CAP] = 0;
+  }
   const int T = a.T, TP = a.TP;
   const double c = a.scal[8 * k];
   const double* Q = a.Q + (size_t)k * TP * TP;
@@ -1593,6 +1598,7 @@ static size_t plan_bytes(int T, int Ts_max, int K, size_t* offs /*[24]*/) {
     for (int i = 0; i < 6; ++i) tmp[12 + i] = take(sz[i]);
     tmp[18] = take((size_t)(K + 1) * sizeof(int32_t));
   }
+  tmp[19] = take((size_t)(PAIRS_FB_CAP + 2) * sizeof(int32_t));   // fall-back list of k_pairs
   if (offs) memcpy(offs, tmp, sizeof(tmp));
   return o;
 }
@@ -1713,6 +1719,11 @@ int hgp_pairs_plan_create(hgp_pairs_plan** plan, int T, int Ts_max, int K, const
   p->d_mu = (double*)(base + offs[16]);
   p->d_sscr = (double*)(base + offs[17]);
   p->d_acc_list = (int32_t*)(base + offs[18]);
+  p->d_fb = (int32_t*)(base + offs[19]);
+  if (hipMemset(p->d_fb, 0, (size_t)(PAIRS_FB_CAP + 2) * sizeof(int32_t)) != hipSuccess) {
+    delete p;
+    return 1000 + (int)hipGetLastError();
+  }
   if (p->coop) {
     const size_t cap = (p->NB >= 12) ? 48 : (p->NB == 8 ? 24 : 16);
     const size_t over = (size_t)p->NB * p->NB > cap ? (size_t)p->NB * p->NB - cap : 0;
@@ -1767,7 +1778,7 @@ int hgp_pairs_plan_update(hgp_pairs_plan* p, const double* x_basis, const double
   launch_gemm(g1, K, st);
   launch_gemm(g2, K, st);
   launch_gemm(g3, K, st);
-  PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap, p->coop ? 0 : 1};
+  PrepFinalArgs fin{p->d_Q, p->d_Kinv, mean, p->d_scal, T, TP, p->d_Mp, p->d_ap, p->coop ? 0 : 1, p->d_fb};
   hipLaunchKernelGGL(k_prep_final, dim3(K, 8), dim3(256), 0, st, fin);
   // overflow-area flags: a launch that was killed mid-flight must not leave areas marked busy for the next one
   if (p->d_eflags && p->nscr > 0 && hipMemsetAsync(p->d_eflags, 0, (p->nscr + 1) * sizeof(int32_t), st) != hipSuccess) return launch_status();
@@ -1803,7 +1814,7 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
                 hgp_internal_stamp_dev,
 #endif
                 p->K, out_quad, out_logdet, out_info, p->d_escr, p->d_eflags, p->nscr, p->escr_stride,
-                env_on("HGP_PAIRS_GENERIC") ? 1 : 0};
+                env_on("HGP_PAIRS_GENERIC") ? 1 : 0, p->d_fb};
     rc = hgp_internal_pairs_fast(a, p->NB, p->coop, st);
   }
   if (rc == 0) rc = hgp_internal_pairs_acc(p, x, y, N, Ts, first_noise, sel, out_quad, out_logdet, out_info, st);

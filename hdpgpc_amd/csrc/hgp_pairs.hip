@@ -79,6 +79,29 @@ struct PairsBand {
       }
     return Item{0, 0, 0, 0, 0, 0, 0};
   }
+  // sweep 2 of pass (J, h) as a flat list of groups (row tile i of the panel, column I <= J) with block (NH h + i, I) of E active
+  struct Group {
+    int i, I;
+  };
+  static constexpr int ngroups(int J, int h) {
+    int cnt = 0;
+    for (int i = 0; i < NH; ++i)
+      if ((rows(J, h) >> i) & 1)
+        for (int I = 0; I <= J; ++I)
+          if ((emask(I) >> (NH * h + i)) & 1) ++cnt;
+    return cnt;
+  }
+  static constexpr Group group(int J, int h, int n) {
+    int cnt = 0;
+    for (int i = 0; i < NH; ++i)
+      if ((rows(J, h) >> i) & 1)
+        for (int I = 0; I <= J; ++I)
+          if ((emask(I) >> (NH * h + i)) & 1) {
+            if (cnt == n) return Group{i, I};
+            ++cnt;
+          }
+    return Group{0, 0};
+  }
   static constexpr int nitems() {
     int cnt = 0;
     for (int J = 0; J < NB; ++J)
@@ -90,7 +113,11 @@ struct PairsBand {
 
 template <int NB>
 __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const double* __restrict__ Mbase, const double* E,
-                                            int lane_in, double cc, double noise, int Ts) {
+                                            int lane_in, double cc, double noise, int Ts
+#ifdef HGP_STAMPS
+                                            , unsigned long long& hgp_t_, unsigned long long (&hgp_acc_)[8]
+#endif
+) {
   using PB = PairsBand<NB>;
   constexpr int TP = 16 * NB, NH = NB / 2, NI = PB::nitems();
   double ra[4][2][NH], re[4][2];
@@ -140,6 +167,18 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
     if constexpr (it.last) {
       const int ln = launder(lane_in);
       const int g = ln >> 4, c = ln & 15;
+      HGP_ACC(1);
+      constexpr int NG = PB::ngroups(J, h);
+      double af[2][4];
+      auto ldaf = [&](auto nc) {
+        constexpr int n_ = decltype(nc)::value;
+        if constexpr (n_ < NG) {
+          constexpr auto gp = PB::group(J, h, n_);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) af[n_ & 1][r] = E[(16 * (NH * h + gp.i) + 4 * r + g) * TP + 16 * gp.I + c];
+        }
+      };
+      ldaf(std::integral_constant<int, 0>{});
       if constexpr (h == 0) {   // K** seeds of column J (cached tiles, see k_pairs) + the exact diagonal
 #pragma unroll
         for (int I = 0; I <= J; ++I) {
@@ -156,22 +195,20 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
           cov[tix(I, J, NB)] = kt;
         }
       }
-      // sweep 2: cov[I][J] += E[Kt, I]^T BJ[Kt] over the blocks |Kt - I| <= 1, I <= J
+      HGP_ACC(2);
+      // sweep 2: cov[I][J] += E[Kt, I]^T BJ[Kt] over the blocks |Kt - I| <= 1, I <= J.  The A operand of group n + 1 is requested
+      // from LDS before the four MFMAs of group n are issued (the compiler left the reads one MFMA ahead of their use:
+      // 41 k cycles for 396 MFMAs, 25 k at the issue rate)
+      {
+        static_for<0, NG>([&](auto nc) {
+          constexpr int n_ = decltype(nc)::value;
+          constexpr auto gp = PB::group(J, h, n_);
+          ldaf(std::integral_constant<int, n_ + 1>{});
 #pragma unroll
-      for (int i = 0; i < NH; ++i) {
-        if ((rm >> i) & 1) {
-#pragma unroll
-          for (int I = 0; I <= J; ++I) {
-            if ((PB::emask(I) >> (NH * h + i)) & 1) {
-              double af[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) af[r] = E[(16 * (NH * h + i) + 4 * r + g) * TP + 16 * I + c];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) cov[tix(I, J, NB)] = mfma(af[r], BJ[i][r], cov[tix(I, J, NB)]);
-            }
-          }
-        }
+          for (int r = 0; r < 4; ++r) cov[tix(gp.I, J, NB)] = mfma(af[n_ & 1][r], BJ[gp.i][r], cov[tix(gp.I, J, NB)]);
+        });
       }
+      HGP_ACC(3);
     }
   });
 }
@@ -181,7 +218,13 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
 // the waves; each wave then evaluates one (segment, cluster) pair entirely in its own registers:
 //   cov = c R_n + noise I + E^T M'_k E   (two MFMA sweeps per column panel, the first result feeding the second
 //   straight from its accumulators), regularise, factor (wave_factor), eliminate d on the VALU, reduce.
-template <int NB>
+//
+// Two instantiations (round 3): k_pairs<NB, true> holds ONLY the static sweeps of a block-tridiagonal E (band_sweeps); a workgroup
+// whose masks do not match that pattern appends its segment to the fall-back list a.fb and leaves, and k_pairs<NB, false> (the
+// mask-driven sweeps, launched right behind on the same grid) takes the listed segments; its other workgroups leave at once.  With both sweep codes in one
+// kernel the allocator spilled 126 VGPRs at NB = 8 (284 B of scratch per lane, 189 MB of scratch writes per launch, WRITE_SIZE);
+// apart they need none.  Without a list (a.fb == nullptr: NB < 6, HGP_PAIRS_GENERIC=1) the generic kernel takes every segment.
+template <int NB, bool BAND>
 __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   constexpr int TP = 16 * NB;
   constexpr int NH = NB / 2;
@@ -194,8 +237,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   double* scr = xbs + TP + wave * DIAG_SCR;
   double* dall = xbs + TP + WAVES * DIAG_SCR;   // [PAIRS_DCOLS][TP]: d = y - E^T a' of the clusters of the current chunk, then z = L^{-1} d
   int* amask = reinterpret_cast<int*>(dall + PAIRS_DCOLS * TP);   // bit Kt of amask[J]: block (Kt, J) of E active
-  const int n = blockIdx.x;
   const int T = a.T, Ts = a.Ts;
+  int n = blockIdx.x, total = 0;
+  if constexpr (!BAND) {
+    if (a.fb) {   // the list is complete (previous kernel on the stream); workgroups beyond it have nothing to do
+      total = a.fb[0];
+      if (n >= total) return;
+      n = a.fb[1 + n];
+    }
+  }
 
   // Padding (i >= Ts, k >= T) uses far-apart sentinels instead of bounds predicates: every kernel entry that
   // involves a padded point is then exp(-huge) = 0 by itself (all differences stay finite: < 3e152).
@@ -257,6 +307,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #pragma unroll
   for (int J = 0; J < NB; ++J) band = band && amask[J] == PairsBand<NB>::emask(J) && kmask[J] == PairsBand<NB>::kmask(J);
   band = __builtin_amdgcn_readfirstlane((int)band) != 0;
+  if constexpr (BAND) {
+    if (!band) {   // not the static pattern: this segment goes to the generic kernel
+      if (tid == 0) a.fb[1 + atomicAdd(&a.fb[0], 1)] = n;
+      return;
+    }
+  }
   if (kcache) {
     const int lane = tid & 63, g = lane >> 4, c = lane & 15;
     for (int t = wave; t < NB * NB; t += WAVES) {
@@ -354,8 +410,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #else
     const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP;   // + column offset inside HGP_FILL (interleaved)
 #endif
-    if (band) {
-      band_sweeps<NB>(cov, Mbase, E, lane, cc, noise, Ts);
+    if constexpr (BAND) {
+      band_sweeps<NB>(cov, Mbase, E, lane, cc, noise, Ts
+#ifdef HGP_STAMPS
+                      , hgp_t_, hgp_acc_
+#endif
+      );
     } else {
     // Sweep-1 operand ring: 4 slots of half a k-block each (2 k-steps: 2 x NH rows of M' from L2 + 2 values of E
     // from LDS).  A slot is refilled right after its MFMAs are issued, i.e. three half-blocks (about 1.5k cycles
@@ -549,6 +609,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   if ((tid & 63) == 0 && a.stamps)
     for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
 #endif
+  if constexpr (!BAND) {   // the last LISTED workgroup to finish hands the list back empty; an unlisted one that reads the count after that
+                           // sees 0 and leaves as it would have before
+    if (a.fb && tid == 0) {
+      __threadfence();
+      if (atomicAdd(&a.fb[1 + PAIRS_FB_CAP], 1) == total - 1) {
+        a.fb[0] = 0;
+        a.fb[1 + PAIRS_FB_CAP] = 0;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------ a2 + a5, cooperative: one workgroup per pair
@@ -938,10 +1008,30 @@ int launch_pairs_cooph(const PairsArgs& a, hipStream_t st) {
 }
 
 template <int NB>
-int launch_pairs(const PairsArgs& a, hipStream_t st) {
+int launch_pairs(const PairsArgs& a0, hipStream_t st) {
   size_t lds = pairs_lds_bytes<NB>();
-  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs<NB>), lds)) return rc_;
-  hipLaunchKernelGGL(k_pairs<NB>, dim3(a.N), dim3(64 * WAVES), lds, st, a);
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs<NB, false>), lds)) return rc_;
+  if (NB < 6 || (a0.flags & 1) || !a0.fb) {   // mask-driven sweeps for every segment
+    PairsArgs a = a0;
+    a.fb = nullptr;
+    hipLaunchKernelGGL((k_pairs<NB, false>), dim3(a.N), dim3(64 * WAVES), lds, st, a);
+    return launch_status();
+  }
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs<NB, true>), lds)) return rc_;
+  for (int off = 0; off < a0.N; off += PAIRS_FB_CAP) {   // the fall-back list holds PAIRS_FB_CAP segments
+    PairsArgs a = a0;
+    a.N = std::min(PAIRS_FB_CAP, a0.N - off);
+    const size_t oo = a.sel ? (size_t)off : (size_t)off * a.K;
+    a.x += (size_t)off * a.Ts;
+    a.y += (size_t)off * a.Ts;
+    if (a.first_noise) a.first_noise += oo;
+    if (a.sel) a.sel += off;
+    a.out_quad += oo;
+    if (a.out_logdet) a.out_logdet += oo;
+    if (a.out_info) a.out_info += oo;
+    hipLaunchKernelGGL((k_pairs<NB, true>), dim3(a.N), dim3(64 * WAVES), lds, st, a);
+    hipLaunchKernelGGL((k_pairs<NB, false>), dim3(a.N), dim3(64 * WAVES), lds, st, a);
+  }
   return launch_status();
 }
 

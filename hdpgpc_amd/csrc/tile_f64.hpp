@@ -77,6 +77,14 @@ __device__ __forceinline__ double launder_f64(double x) {
   return x;
 }
 
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, B>), ..., f(integral_constant<int, E - 1>)
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 // All-reduce over the 64 lanes without the LDS crossbar: inside each row of 16 lanes by DPP rotations (row_ror 8, 4, 2,
 // 1: after the four steps every lane holds its row's result), across the four rows with the gfx950 permlane swaps.
 // About 25 VALU instructions against 12 ds_bpermute round trips for the shuffle butterfly (k_hmm_messages: 0.77 -> 0.51 us per step).
@@ -460,15 +468,175 @@ __device__ __forceinline__ d4 diag16_col(const d4& X, double* scr, int lane, Piv
   return w;
 }
 
+// ---------------------------------------------------------------------------------------------
+// diag16_acc (round 3, third session): the elimination IN the accumulator layout, all 64 lanes busy.  The other VALU forms hold one
+// column per lane (16 + 16 lanes, sixteen registers, 15 multiplier broadcasts + 15 FMAs per step: ~950 instructions per block, which
+// is what their ~4.2 k cycles are).  Here lane (g, c) keeps S[4r + g][c] in register r exactly as the MFMA left it - no staging
+// through LDS on the way in - and step k is a rank-1 update of the whole tile in (4 - k/4) FMAs:
+//   * the pivot p_k = S[k][k] goes through v_readlane (uniform, SGPR pair), 1/p_k by v_rcp_f64 + one third-order step;
+//   * row k is copied to the four 16-lane rows of the wave by v_permlane16_swap + v_permlane32_swap (s_k[c] in every lane (., c));
+//   * the multipliers S[i][k] of the rows below come from v_mov_dpp row_newbcast:k of the tile registers themselves (the Schur
+//     complement stays symmetric, so column k IS the multiplier column); rows of the pivot's own register that are already done
+//     get a zero multiplier through the DPP row mask;
+//   * Z (= I at the start) takes the same row operations with the same multipliers: Z[i][.] -= (S[i][k] / p_k) Z[k][.];
+//   * rows stay UNSCALED during the elimination (as in diag16_col): the sixteen 1/sqrt(p_k) are one rsqrt sequence at the end
+//     (lane c holds p_c), the scaling of W = D^{-1/2} Z happens in the final transposition to the A-operand layout, the pivot
+//     product / first bad pivot are one DPP reduction and one ballot.
+// Finished rows are not protected: row k of S becomes ~0 after its step and only ever feeds itself again (dead rows and columns
+// of the symmetric Schur complement never reach a live entry).  ~470 instructions per block, dependency chain ~80 cycles per pivot.
+// Same interface as the other forms; results agree to rounding (multipliers S/p instead of (S/sqrt p)(S/sqrt p)).
+// ---------------------------------------------------------------------------------------------
+template <int G0>
+__device__ __forceinline__ double row_to_all(double v) {   // row G0 (16 lanes) of v copied to all four rows of the wave
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // a[0] = rows (0,0,2,2), a[1] = rows (1,1,3,3)
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const unsigned lo1 = a[G0 & 1], hi1 = b[G0 & 1];
+  const auto a2 = __builtin_amdgcn_permlane32_swap(lo1, lo1, false, false);   // [0] = lower half twice, [1] = upper half twice
+  const auto b2 = __builtin_amdgcn_permlane32_swap(hi1, hi1, false, false);
+  return __hiloint2double((int)b2[G0 >> 1], (int)a2[G0 >> 1]);
+}
+// the same through the LDS crossbar (ds_bpermute_b32 x 2, no LDS memory): two instructions that do not occupy the VALU, ~30 cycles
+__device__ __forceinline__ double row_to_all_bperm(double v, int addr) {   // addr = 4 (16 G0 + c)
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// One elimination step on the registers of S and of Z:  X[r] += bcast_{4r}(mrot) * t  for the rows below pivot K.  mrot is row K
+// of S copied to the four rows of the wave with row g rotated by g lanes, so that lane 4r of row g holds S[K][4r + g] - the
+// multiplier of row 4r + g - and ONE DPP control (row_newbcast:4r inside v_fmac_f64_dpp) serves all four rows; the DPP row mask
+// keeps the finished rows of the pivot's own register.  The multipliers are taken from ROW K (upper triangle), never from column
+// K: rounding makes the two differ, and a first version that read column K lost two digits on ill-conditioned blocks
+// (k_pairs_acc at length-scale 3: 1e-7 instead of 5e-10).  (s_nop 1: a DPP source written by the preceding VALU instruction
+// needs two wait states, and the hazard recogniser does not look inside inline assembly.)
+template <int RS, int RMF>   // register RS (the one that holds row K + 1: on the pivot chain); row mask RMF
+__device__ __forceinline__ void elim_crit(double (&S)[4], double (&Z)[4], double mrot, double nt, double ntz) {
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:%6 bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:%6 bank_mask:0xf"
+      : "+v"(S[RS]), "+v"(Z[RS])
+      : "v"(mrot), "v"(nt), "v"(ntz), "n"(4 * RS), "n"(RMF));
+}
+template <int RS>   // registers RS + 1 .. 3 (all rows): off the chain, issued behind the next pivot's broadcasts
+__device__ __forceinline__ void elim_rest(double (&S)[4], double (&Z)[4], double mrot, double nt, double ntz) {
+#define HGP_FD(dst, mul, lane) "v_fmac_f64_dpp %" #dst ", %6, %" #mul " row_newbcast:" #lane " row_mask:0xf bank_mask:0xf\n\t"
+  if constexpr (RS == 0) {
+    asm("s_nop 1\n\t" HGP_FD(0, 7, 4) HGP_FD(1, 7, 8) HGP_FD(2, 7, 12) HGP_FD(3, 8, 4) HGP_FD(4, 8, 8) HGP_FD(5, 8, 12)
+        : "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(Z[1]), "+v"(Z[2]), "+v"(Z[3])
+        : "v"(mrot), "v"(nt), "v"(ntz));
+  } else if constexpr (RS == 1) {
+    asm("s_nop 1\n\t" HGP_FD(1, 7, 8) HGP_FD(2, 7, 12) HGP_FD(4, 8, 8) HGP_FD(5, 8, 12)
+        : "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(Z[1]), "+v"(Z[2]), "+v"(Z[3])
+        : "v"(mrot), "v"(nt), "v"(ntz));
+  } else if constexpr (RS == 2) {
+    asm("s_nop 1\n\t" HGP_FD(2, 7, 12) HGP_FD(5, 8, 12)
+        : "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(Z[1]), "+v"(Z[2]), "+v"(Z[3])
+        : "v"(mrot), "v"(nt), "v"(ntz));
+  }
+#undef HGP_FD
+}
+
+__device__ __forceinline__ d4 diag16_acc(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
+                                         double* Lout, int ldl, int nvalid) {
+  const int g = lane >> 4, c = lane & 15;
+#ifdef HGP_EXP_NODIAG   // in-situ knock-out experiment (diagnostic builds only)
+  {
+    d4 w;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = (4 * s + g == c) ? 1.0 / sqrt(fabs(X[s]) + 1.0) : 0.0;
+    pa.mant *= 1.0 + 1e-300 * X[0];
+    return w;
+  }
+#endif
+#ifdef HGP_STAMPS
+  const unsigned long long td0 = __builtin_readcyclecounter();
+#endif
+  double S[4], Z[4];
+  d4 Us;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    S[r] = X[r];
+    Z[r] = (4 * r + g == c) ? 1.0 : 0.0;
+    Us[r] = 0.0;
+  }
+  int pvlo = 0, pvhi = 0;   // p_k in lane k (row 0 of the wave), collected with v_writelane
+  // software pipeline: the pivot and the row copies of step k + 1 are requested right behind the two FMAs that finish row
+  // k + 1 (elim_crit); the other FMAs of step k (elim_rest) issue under their latency
+  const int crot = (c + g) & 15;
+  double p = lane_bcast(S[0], 0);
+  double sk = row_to_all_bperm(S[0], 4 * c), mrot = row_to_all_bperm(S[0], 4 * crot), zk = row_to_all_bperm(Z[0], 4 * c);
+  static_for<0, 15>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, r0 = k >> 2, g0 = k & 3;
+    constexpr int RS = (g0 == 3) ? r0 + 1 : r0;                          // register of row k + 1
+    constexpr int RMF = (g0 == 3) ? 0xf : (0xf << (g0 + 1)) & 0xf;      // its rows below the pivot
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(k));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(k));
+    const double rp = rcp_nr(p);
+    if (Lout != nullptr) Us[r0] = (g == g0) ? sk : Us[r0];
+    const double nt = -(sk * rp), ntz = -(zk * rp), mr = mrot;
+    elim_crit<RS, RMF>(S, Z, mr, nt, ntz);
+    constexpr int k1 = k + 1, g1 = k1 & 3;
+    p = lane_bcast(S[RS], 16 * g1 + k1);
+    if constexpr (k1 < 15) {
+      sk = row_to_all_bperm(S[RS], 4 * (16 * g1 + c));
+      mrot = row_to_all_bperm(S[RS], 4 * (16 * g1 + crot));
+      zk = row_to_all_bperm(Z[RS], 4 * (16 * g1 + c));
+    }
+    elim_rest<RS>(S, Z, mr, nt, ntz);
+  });
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(15));
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(15));
+  if (Lout != nullptr) Us[3] = (g == 3) ? S[3] : Us[3];
+  // the pivots: lane c of row 0 holds p_c; every row needs it for the scaling of its part of W
+  const double pv = row_to_all<0>(__hiloint2double(pvhi, pvlo));
+  const double rc = rsqrt_nr(pv);                          // NaN for a pivot <= 0 (or NaN): poisons row c of W, info says where
+  {
+    const unsigned long long bad = __ballot(!(pv > 0.0)) & 0xffffull;
+    if (bad != 0 && pa.info == 0) pa.info = col0 + __ffsll((long long)bad);
+    pa.mant *= row16_prod(__builtin_amdgcn_frexp_mant(pv));      // sixteen mantissas in [0.5, 1): no underflow
+    pa.ex += row16_sum_i32(__builtin_amdgcn_frexp_exp(pv));
+    pa.renorm();
+  }
+  if (Lout != nullptr) {   // L[j][i] = U[i][j] = r_i S_i[j] (row i as it stood at its own step)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr[(4 * r + g) * DIAG_LD + c] = Us[r];
+    if (g == 0) scr[c * DIAG_LD + 16] = rc;                  // padding column of the staging tile
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16 && lane < nvalid) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < nvalid) Lout[(size_t)lane * ldl + i] = (i <= lane) ? scr[i * DIAG_LD + lane] * scr[i * DIAG_LD + 16] : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) scr[(4 * r + g) * DIAG_LD + c] = Z[r];   // unscaled Z rows: Zs[i][j], i = 4r+g, j = c
+  __builtin_amdgcn_wave_barrier();
+  d4 w;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) w[s] = scr[c * DIAG_LD + 4 * s + g] * rc;             // W[c][4s+g] = r_c Zs[c][4s+g]
+  __builtin_amdgcn_wave_barrier();
+#ifdef HGP_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  pa.diag_cycles += __builtin_readcyclecounter() - td0;
+#endif
+  return w;
+}
+
 // Which 16 x 16 diagonal-block routine the factorisations use (A/B builds: -DHGP_DIAG_IMPL=0 restores rounds 1-2:
 // diag16_valu where the register budget asks for it, the MFMA-blocked diag16 elsewhere).
 #ifndef HGP_DIAG_IMPL
-#define HGP_DIAG_IMPL 0   // 1 = diag16_col instead of diag16_valu only; 2 = diag16_col everywhere (both measured SLOWER in the kernels: see diag16_col)
+#define HGP_DIAG_IMPL 3   // 3 = diag16_acc everywhere (shipped: k_pairs<8> 1.265 -> 1.121 ms, k_pairs<6> 0.757 -> 0.677, k_pairs_cooph<16> 7.39 -> 6.91 per 16 384 pairs);
+                          // 0 = rounds 1-2 (diag16_valu / MFMA-blocked diag16); 1 / 2 = diag16_col (measured SLOWER in the kernels: see diag16_col); 4 = diag16_acc for the VALU users only
 #endif
 template <bool VALU>
 __device__ __forceinline__ d4 diag16_sel(const d4& X, double* scr, int lane, PivotAcc& pa, int col0, double* Lout, int ldl,
                                          int nvalid) {
-#if HGP_DIAG_IMPL == 2
+#if HGP_DIAG_IMPL == 3
+  return diag16_acc(X, scr, lane, pa, col0, Lout, ldl, nvalid);
+#elif HGP_DIAG_IMPL == 4
+  return VALU ? diag16_acc(X, scr, lane, pa, col0, Lout, ldl, nvalid) : diag16(X, scr, lane, pa, col0, Lout, ldl, nvalid);
+#elif HGP_DIAG_IMPL == 2
   return diag16_col(X, scr, lane, pa, col0, Lout, ldl, nvalid);
 #elif HGP_DIAG_IMPL == 1
   return VALU ? diag16_col(X, scr, lane, pa, col0, Lout, ldl, nvalid) : diag16(X, scr, lane, pa, col0, Lout, ldl, nvalid);
@@ -1229,14 +1397,6 @@ __device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* r
 // must fail a test, not hang the GPU.
 // ---------------------------------------------------------------------------------------------
 constexpr int COOPH_SPIN_LIMIT = 1 << 22;
-
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, B>), ..., f(integral_constant<int, E - 1>)
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
 
 __device__ __forceinline__ void df_publish(int* p, int v, int lane) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -75,11 +75,11 @@ def test_pred_dist_and_latent_golden():
         c, ell, noise = (float(v) for v in g[f"c{i}_theta"])
         gp = IterativeGaussianProcess(RBFWhiteKernel(c, ell, noise), g[f"c{i}_xb"][:, None])
         f, cov = gp.pred_dist(g[f"c{i}_xp"][:, None], g[f"c{i}_xb"][:, None], g[f"c{i}_mean"][:, None], g[f"c{i}_Sigma"])
-        assert relclose(f.cpu().numpy()[:, 0], g[f"c{i}_f"], 1e-7)
-        assert relclose(cov.cpu().numpy(), g[f"c{i}_cov"], 1e-7)
+        assert relclose(f.cpu().numpy()[:, 0], g[f"c{i}_f"], 1e-8)
+        assert relclose(cov.cpu().numpy(), g[f"c{i}_cov"], 1e-8)
         fl, covl = gp.pred_latent_dist(g[f"c{i}_xp"][:, None], g[f"c{i}_xb"][:, None], g[f"c{i}_mean"][:, None], g[f"c{i}_Sigma"])
-        assert relclose(fl.cpu().numpy()[:, 0], g[f"c{i}_f_lat"], 1e-7)
-        assert relclose(covl.cpu().numpy(), g[f"c{i}_cov_lat"], 1e-7)
+        assert relclose(fl.cpu().numpy()[:, 0], g[f"c{i}_f_lat"], 1e-8)
+        assert relclose(covl.cpu().numpy(), g[f"c{i}_cov_lat"], 1e-8)
 
 
 def test_lml_a10_golden():

@@ -9,6 +9,7 @@ template <int WHICH>
 __device__ __forceinline__ d4 call(const d4& X, double* scr, int lane, PivotAcc& pa, double* Lout) {
   if (WHICH == 0) return diag16(X, scr, lane, pa, 0, Lout, 16, 16);
   if (WHICH == 1) return diag16_valu(X, scr, lane, pa, 0, Lout, 16, 16);
+  if (WHICH == 3) return diag16_acc(X, scr, lane, pa, 0, Lout, 16, 16);
   return diag16_col(X, scr, lane, pa, 0, Lout, 16, 16);
 }
 
@@ -80,12 +81,13 @@ int main() {
       for (int k = j; k < i; ++k) a -= L[i][k] * W[k][j];
       W[i][j] = a / L[i][i];
     }
-  const char* names[3] = {"diag16 (MFMA-blocked)", "diag16_valu (readlane)", "diag16_col (LDS bcast)"};
-  for (int which = 0; which < 3; ++which) {
+  const char* names[4] = {"diag16 (MFMA-blocked)", "diag16_valu (readlane)", "diag16_col (LDS bcast)", "diag16_acc (acc layout)"};
+  for (int which = 0; which < 4; ++which) {
     for (int it = 0; it < 2; ++it) {
       if (which == 0) hipLaunchKernelGGL(kd<0>, dim3(1), dim3(64), 0, 0, in, out, cyc, 64);
       if (which == 1) hipLaunchKernelGGL(kd<1>, dim3(1), dim3(64), 0, 0, in, out, cyc, 64);
       if (which == 2) hipLaunchKernelGGL(kd<2>, dim3(1), dim3(64), 0, 0, in, out, cyc, 64);
+      if (which == 3) hipLaunchKernelGGL(kd<3>, dim3(1), dim3(64), 0, 0, in, out, cyc, 64);
       hipDeviceSynchronize();
     }
     hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
