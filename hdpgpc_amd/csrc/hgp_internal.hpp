@@ -26,12 +26,14 @@ static inline bool env_on(const char* name) {
   return v && v[0] && v[0] != '0';
 }
 
-// Entries of E = exp(-h) and of K** / c with h > PAIRS_CUT (value < 1e-36) are dropped block-wise: a 16x16 block
-// whose entries are ALL below that is neither built nor multiplied.  What is dropped changes a covariance entry by
-// less than 2 T max|M'| 1e-36, far below one ulp; with the reference's length-scale 1.2 on a unit-spaced grid only
-// the blocks |Kt - J| <= 1 survive, which removes ~60 % of the MFMA work at T = 128.  The decision is taken from the
-// data (any grid), never from an assumed band structure.
-constexpr double PAIRS_CUT = 82.9;
+// Entries of E = exp(-h) and of K** / c with h > PAIRS_CUT (value < 2^-80 = 8.3e-25) are exact zeros, and a 16x16 block (k_pairs'
+// static sweeps: a 4-row k-step of a block) whose entries are ALL below that is neither built nor multiplied.  What is dropped
+// changes a covariance entry by less than 2 T max|M'| 2^-80 - below one ulp of the entry for every cluster the explicit-operator
+// kernels score (the plan routes c^2 |K~^-1|^2 > 1e7 to the solve-based kernel).  With the reference's length-scale 1.2 on a
+// unit-spaced grid the band is |k - j| <= 12 points: only the blocks |Kt - J| <= 1 survive (~60 % of the MFMA work at T = 128 gone)
+// and, of their 12 k-steps per column panel, 10.  (Rounds 1-3 cut at 1e-36: |k - j| <= 15, no dead k-step.)  The decision is taken
+// from the data (any grid), never from an assumed band structure.
+constexpr double PAIRS_CUT = 55.45177444479562;   // 80 ln 2
 // segments per launch pair of k_pairs<NB, true> / k_pairs<NB, false> (capacity of the fall-back list of the plan)
 constexpr int PAIRS_FB_CAP = 65536;
 

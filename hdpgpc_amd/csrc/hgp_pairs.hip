@@ -57,6 +57,17 @@ struct PairsBand {
   static constexpr int hi(int J) { return J + 1 < NB ? J + 1 : NB - 1; }
   static constexpr int emask(int J) { return ((1 << (hi(J) + 1)) - 1) & ~((1 << lo(J)) - 1); }   // blocks (Kt, J) of E
   static constexpr int kmask(int J) { return ((1 << (J + 1)) - 1) & ~((1 << lo(J)) - 1); }        // tiles (I, J) of K**
+  // k-step s (rows 4 s .. 4 s + 3) of block (Kt, J) of E can hold an entry above the cut-off: with the cut at 2^-80 the band is
+  // |k - j| <= 12 grid points (length-scale 1.2, unit spacing, any jitter below 0.3), so the first k-step of the block above the
+  // diagonal one and the last k-step of the block below it are zero: 10 of 12 k-steps per column panel (-1/6 of both sweeps)
+  static constexpr bool alive(int Kt, int J, int s) { return Kt == J || (Kt == J - 1 && s >= 1) || (Kt == J + 1 && s <= 2); }
+  static constexpr unsigned emask4(int J) {   // bit 4 Kt + s
+    unsigned m = 0;
+    for (int Kt = lo(J); Kt <= hi(J); ++Kt)
+      for (int s = 0; s < 4; ++s)
+        if (alive(Kt, J, s)) m |= 1u << (4 * Kt + s);
+    return m;
+  }
   static constexpr int rows(int J, int h) {   // row tiles NH h + i of B[:, J] that sweep 2 reads: NH h + i <= J + 1
     int m = 0;
     for (int i = 0; i < NH; ++i)
@@ -131,6 +142,7 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
       const int g = lane >> 4, c = lane & 15;
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
+        if (!PB::alive(it.Lt, it.J, 2 * it.hb + s_)) continue;
         const double* row_ = Mbase + 16 * NH * it.h + (size_t)(16 * it.Lt + 4 * (2 * it.hb + s_)) * TP;
 #pragma unroll
         for (int P_ = 0; P_ < NH / 2; ++P_) {
@@ -159,6 +171,7 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
     }
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
+      if (!PB::alive(it.Lt, it.J, 2 * it.hb + s_)) continue;
 #pragma unroll
       for (int i = 0; i < NH; ++i)
         if ((rm >> i) & 1) BJ[i] = mfma(ra[slot][s_][i], re[slot][s_], BJ[i]);
@@ -175,7 +188,8 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
         if constexpr (n_ < NG) {
           constexpr auto gp = PB::group(J, h, n_);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) af[n_ & 1][r] = E[(16 * (NH * h + gp.i) + 4 * r + g) * TP + 16 * gp.I + c];
+          for (int r = 0; r < 4; ++r)
+            if (PB::alive(NH * h + gp.i, gp.I, r)) af[n_ & 1][r] = E[(16 * (NH * h + gp.i) + 4 * r + g) * TP + 16 * gp.I + c];
         }
       };
       ldaf(std::integral_constant<int, 0>{});
@@ -205,7 +219,8 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
           constexpr auto gp = PB::group(J, h, n_);
           ldaf(std::integral_constant<int, n_ + 1>{});
 #pragma unroll
-          for (int r = 0; r < 4; ++r) cov[tix(gp.I, J, NB)] = mfma(af[n_ & 1][r], BJ[gp.i][r], cov[tix(gp.I, J, NB)]);
+          for (int r = 0; r < 4; ++r)
+            if (PB::alive(NH * h + gp.i, gp.I, r)) cov[tix(gp.I, J, NB)] = mfma(af[n_ & 1][r], BJ[gp.i][r], cov[tix(gp.I, J, NB)]);
         });
       }
       HGP_ACC(3);
@@ -255,7 +270,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     xbs[i] = (i < T) ? a.xb[i] / a.ell : -1e150 * (double)(1 + i);
   }
   int* kmask = amask + 8;   // bit I of kmask[J]: tile (I, J) of K** has an entry above the cut-off (I <= J)
-  if (tid < 16) amask[tid] = 0;
+  int* amask4 = amask + 16;  // bit 4 Kt + s of amask4[J]: k-step s of block (Kt, J) of E has an entry above the cut-off
+  if (tid < 24) amask[tid] = 0;
   __syncthreads();
   {
     const int lane = tid & 63, g = lane >> 4, c = lane & 15;
@@ -271,10 +287,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
         h[r] = 0.5 * (u * u);
         near = near || (h[r] < PAIRS_CUT);
       }
-      if (__any(near)) {
+      if (__any(near)) {   // entries below the cut-off are exact zeros: a k-step of the block made of zeros only can be skipped bit for bit
+        unsigned ks = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) E[(16 * Kt + g + 4 * r) * TP + j] = HGP_EXPF(-h[r]);
-        if (lane == 0) atomicOr(&amask[Jb], 1 << Kt);
+        for (int r = 0; r < 4; ++r) {
+          E[(16 * Kt + g + 4 * r) * TP + j] = (h[r] < PAIRS_CUT) ? HGP_EXPF(-h[r]) : 0.0;
+          if (__any(h[r] < PAIRS_CUT)) ks |= 1u << r;
+        }
+        if (lane == 0) {
+          atomicOr(&amask[Jb], 1 << Kt);
+          if (NB <= 8) atomicOr(&amask4[Jb], (int)(ks << (4 * Kt)));
+        }
       }
     }
     for (int t = wave; t < NB * NB; t += WAVES) {   // same test for the tiles of K** (upper ones)
@@ -305,7 +328,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   // block-tridiagonal E and K** (the reference's setting): the static sweeps (band_sweeps) instead of the mask-driven ones
   bool band = (NB >= 6) && kcache && !(a.flags & 1);
 #pragma unroll
-  for (int J = 0; J < NB; ++J) band = band && amask[J] == PairsBand<NB>::emask(J) && kmask[J] == PairsBand<NB>::kmask(J);
+  for (int J = 0; J < NB; ++J)
+    band = band && amask[J] == PairsBand<NB>::emask(J) && kmask[J] == PairsBand<NB>::kmask(J) &&
+           ((unsigned)amask4[J] & ~PairsBand<NB>::emask4(J)) == 0u;   // every k-step with an entry is one the static sweeps multiply
   band = __builtin_amdgcn_readfirstlane((int)band) != 0;
   if constexpr (BAND) {
     if (!band) {   // not the static pattern: this segment goes to the generic kernel
@@ -322,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double u = xs[16 * I + g + 4 * r] - xs[16 * J + c];
-        E[(16 * Kh + g + 4 * r) * TP + 16 * J + c] = HGP_EXPF(-0.5 * (u * u));
+        E[(16 * Kh + g + 4 * r) * TP + 16 * J + c] = (0.5 * (u * u) < PAIRS_CUT) ? HGP_EXPF(-0.5 * (u * u)) : 0.0;
       }
     }
   }
@@ -535,7 +560,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
-                  kt[r] = cc * HGP_EXPF(-0.5 * (u * u));
+                  kt[r] = (0.5 * (u * u) < PAIRS_CUT) ? cc * HGP_EXPF(-0.5 * (u * u)) : 0.0;
                 }
               }
             }
