@@ -24,6 +24,7 @@ def _load():
     sigs = {
         "hgp_abi_version": (i32, []),
         "hgp_debug_mfma_f64": (i32, [vp, vp, vp, vp]),
+        "hgp_debug_exp_neg_f64": (i32, [vp, i32, vp, vp]),
         "hgp_gram_rbf_f64": (i32, [vp, i32, vp, i32, f64, f64, f64, vp, vp]),
         "hgp_potrf_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, vp]),
         "hgp_chol_inverse_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp]),

@@ -40,6 +40,19 @@ __global__ void k_mfma_probe(const double* __restrict__ A, const double* __restr
   for (int r = 0; r < 4; ++r) C[(g + 4 * r) * 16 + c] = acc[r];
 }
 
+// diagnostics: the kernels' own exp(-h), four values per lane
+__global__ void k_exp_probe(const double* __restrict__ h, int n, double* __restrict__ out) {
+  const int i = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (i + 3 >= n + 0 && i >= n) return;
+  double hv[4], ev[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) hv[j] = (i + j < n) ? h[i + j] : 0.0;
+  exp_neg4(hv, ev);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (i + j < n) out[i + j] = ev[j];
+}
+
 // ------------------------------------------------------------------------------------------ a3
 struct PotrfArgs {
   double* A;
@@ -1610,6 +1623,13 @@ int hgp_abi_version(void) { return HGP_ABI_VERSION; }
 int hgp_debug_mfma_f64(const double* A, const double* B, double* C, void* stream) {
   if (!A || !B || !C) return -1;
   hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, C);
+  return launch_status();
+}
+
+int hgp_debug_exp_neg_f64(const double* h, int n, double* out, void* stream) {
+  if (!h || !out || n < 0) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_exp_probe, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, h, n, out);
   return launch_status();
 }
 

@@ -18,9 +18,9 @@ using namespace hgp;
 #endif
 // in-situ knock-out experiments (diagnostic builds only; results are wrong by construction)
 #ifdef HGP_EXP_NOEXP
-#define HGP_EXPF(x) (1.0 / (1.0 - (x)))
+#define HGP_EXP4(h, o) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) (o)[i_] = 1.0 / (1.0 + (h)[i_])
 #else
-#define HGP_EXPF(x) exp(x)
+#define HGP_EXP4(h, o) exp_neg4(h, o)
 #endif
 
 namespace {
@@ -126,7 +126,7 @@ template <int NB>
 __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const double* __restrict__ Mbase, const double* E,
                                             int lane_in, double cc, double noise, int Ts
 #ifdef HGP_STAMPS
-                                            , unsigned long long& hgp_t_, unsigned long long (&hgp_acc_)[8]
+                                            , unsigned long long& hgp_t_, unsigned long long (&hgp_acc_)[12]
 #endif
 ) {
   using PB = PairsBand<NB>;
@@ -253,6 +253,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   double* dall = xbs + TP + WAVES * DIAG_SCR;   // [PAIRS_DCOLS][TP]: d = y - E^T a' of the clusters of the current chunk, then z = L^{-1} d
   int* amask = reinterpret_cast<int*>(dall + PAIRS_DCOLS * TP);   // bit Kt of amask[J]: block (Kt, J) of E active
   const int T = a.T, Ts = a.Ts;
+  HGP_STAMP_DECL
+  HGP_T0();
   int n = blockIdx.x, total = 0;
   if constexpr (!BAND) {
     if (a.fb) {   // the list is complete (previous kernel on the stream); workgroups beyond it have nothing to do
@@ -273,86 +275,115 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   int* amask4 = amask + 16;  // bit 4 Kt + s of amask4[J]: k-step s of block (Kt, J) of E has an entry above the cut-off
   if (tid < 24) amask[tid] = 0;
   __syncthreads();
+#ifdef HGP_STAMPS
+  { unsigned long long n_ = __builtin_readcyclecounter(); hgp_acc_[8] += n_ - hgp_t_; }
+#endif
   {
+    // Wave w owns the column blocks Jb = w, w + WAVES, ...: it tests every block (Kt, Jb) of E and every tile (I <= Jb, Jb) of K**
+    // against the cut-off and builds the active blocks.  The lane's rows of both grids sit in registers after ONE LDS round trip
+    // (the loop over blocks used to wait for five LDS reads per block: 19 k cycles for the two test loops, in-kernel stamps),
+    // and the masks of a column are plain stores by its owner (no atomics).
     const int lane = tid & 63, g = lane >> 4, c = lane & 15;
-    for (int blk = wave; blk < NB * NB; blk += WAVES) {
-      const int Kt = blk / NB, Jb = blk % NB;
-      const int j = 16 * Jb + c;
-      double h[4];
-      bool near = false;
+    double xbr[NB][4], xsr[NB][4];
+#pragma unroll
+    for (int Kt = 0; Kt < NB; ++Kt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int k = 16 * Kt + g + 4 * r;
-        const double u = xbs[k] - xs[j];
-        h[r] = 0.5 * (u * u);
-        near = near || (h[r] < PAIRS_CUT);
-      }
-      if (__any(near)) {   // entries below the cut-off are exact zeros: a k-step of the block made of zeros only can be skipped bit for bit
-        unsigned ks = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          E[(16 * Kt + g + 4 * r) * TP + j] = (h[r] < PAIRS_CUT) ? HGP_EXPF(-h[r]) : 0.0;
-          if (__any(h[r] < PAIRS_CUT)) ks |= 1u << r;
-        }
-        if (lane == 0) {
-          atomicOr(&amask[Jb], 1 << Kt);
-          if (NB <= 8) atomicOr(&amask4[Jb], (int)(ks << (4 * Kt)));
-        }
+        xbr[Kt][r] = xbs[16 * Kt + g + 4 * r];
+        xsr[Kt][r] = xs[16 * Kt + g + 4 * r];
       }
     }
-    for (int t = wave; t < NB * NB; t += WAVES) {   // same test for the tiles of K** (upper ones)
-      const int I = t / NB, J = t % NB;
-      if (I > J) continue;
-      bool near = false;
+    for (int Jb = wave; Jb < NB; Jb += WAVES) {
+      const int j = 16 * Jb + c;
+      const double xj = xs[j];
+      unsigned am = 0, a4 = 0, km = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double u = xs[16 * I + g + 4 * r] - xs[16 * J + c];
-        near = near || (0.5 * (u * u) < PAIRS_CUT);
+      for (int Kt = 0; Kt < NB; ++Kt) {
+        double h[4];
+        bool near = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double u = xbr[Kt][r] - xj;
+          h[r] = 0.5 * (u * u);
+          near = near || (h[r] < PAIRS_CUT);
+        }
+        if (__any(near)) {   // entries below the cut-off are exact zeros: a k-step of the block made of zeros only can be skipped bit for bit
+          double ev[4];
+          HGP_EXP4(h, ev);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            E[(16 * Kt + g + 4 * r) * TP + j] = (h[r] < PAIRS_CUT) ? ev[r] : 0.0;
+            if (__any(h[r] < PAIRS_CUT)) a4 |= 1u << ((4 * Kt + r) & 31);
+          }
+          am |= 1u << Kt;
+        }
+        if (Kt <= Jb) {   // the same test for tile (Kt, Jb) of K** (upper tiles)
+          bool nk = false;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double u = xsr[Kt][r] - xj;
+            nk = nk || (0.5 * (u * u) < PAIRS_CUT);
+          }
+          if (__any(nk)) km |= 1u << Kt;
+        }
       }
-      if (__any(near) && lane == 0) atomicOr(&kmask[J], 1 << I);
+      if (lane == 0) {
+        amask[Jb] = (int)am;
+        kmask[Jb] = (int)km;
+        if (NB <= 8) amask4[Jb] = (int)a4;
+      }
     }
   }
   __syncthreads();
 
+#ifdef HGP_STAMPS
+  { unsigned long long n_ = __builtin_readcyclecounter(); hgp_acc_[9] += n_ - hgp_t_; }
+#endif
   // K** = c exp(-0.5 (x_i - x_j)^2 / ell^2) depends on the segment only: its active tiles (without the factor c) are built ONCE
   // per workgroup and kept in blocks of the E array that E itself does not use - tile (I, J) in block ((I + NB/2) % NB, J) -
   // instead of 4 exp per lane and tile in every pair (16 k of a pair's 246 k cycles at T = 128).  Decided from the
   // data: if any home block is an active block of E (dense grids, NB < 6) the pairs compute the tiles themselves as before.
-  bool kcache = (NB >= 6);
+  // (all masks are read first and combined with bit operations: the short-circuit form made 24 dependent LDS round trips, 3.7 k cycles)
+  int kbad = 0, bbad = 0;
 #pragma unroll
   for (int J = 0; J < NB; ++J) {
-    const int km = kmask[J], rot = ((km << NH) | (km >> (NB - NH))) & ((1 << NB) - 1);
-    kcache = kcache && ((rot & amask[J]) == 0);
+    const int km = kmask[J], am = amask[J], a4 = (NB <= 8) ? amask4[J] : 0;
+    const int rot = ((km << NH) | (km >> (NB - NH))) & ((1 << NB) - 1);
+    kbad |= rot & am;
+    // block-tridiagonal E and K** (the reference's setting) with every live k-step one that the static sweeps multiply
+    bbad |= (am ^ PairsBand<NB>::emask(J)) | (km ^ PairsBand<NB>::kmask(J)) | (int)((unsigned)a4 & ~PairsBand<NB>::emask4(J));
   }
-  kcache = __builtin_amdgcn_readfirstlane((int)kcache) != 0;
-  // block-tridiagonal E and K** (the reference's setting): the static sweeps (band_sweeps) instead of the mask-driven ones
-  bool band = (NB >= 6) && kcache && !(a.flags & 1);
-#pragma unroll
-  for (int J = 0; J < NB; ++J)
-    band = band && amask[J] == PairsBand<NB>::emask(J) && kmask[J] == PairsBand<NB>::kmask(J) &&
-           ((unsigned)amask4[J] & ~PairsBand<NB>::emask4(J)) == 0u;   // every k-step with an entry is one the static sweeps multiply
-  band = __builtin_amdgcn_readfirstlane((int)band) != 0;
+  const bool kcache = (NB >= 6) && __builtin_amdgcn_readfirstlane(kbad) == 0;
+  // -> the static sweeps (band_sweeps) instead of the mask-driven ones
+  const bool band = (NB >= 6) && kcache && !(a.flags & 1) && __builtin_amdgcn_readfirstlane(bbad) == 0;
   if constexpr (BAND) {
     if (!band) {   // not the static pattern: this segment goes to the generic kernel
       if (tid == 0) a.fb[1 + atomicAdd(&a.fb[0], 1)] = n;
       return;
     }
   }
+#ifdef HGP_STAMPS
+  { unsigned long long n_ = __builtin_readcyclecounter(); hgp_acc_[10] += n_ - hgp_t_; }
+#endif
   if (kcache) {
     const int lane = tid & 63, g = lane >> 4, c = lane & 15;
     for (int t = wave; t < NB * NB; t += WAVES) {
       const int I = t / NB, J = t % NB;
       if (I > J || !((kmask[J] >> I) & 1)) continue;
       const int Kh = (I + NH) % NB;
+      double hk[4], ev[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double u = xs[16 * I + g + 4 * r] - xs[16 * J + c];
-        E[(16 * Kh + g + 4 * r) * TP + 16 * J + c] = (0.5 * (u * u) < PAIRS_CUT) ? HGP_EXPF(-0.5 * (u * u)) : 0.0;
+        hk[r] = 0.5 * (u * u);
       }
+      HGP_EXP4(hk, ev);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) E[(16 * Kh + g + 4 * r) * TP + 16 * J + c] = (hk[r] < PAIRS_CUT) ? ev[r] : 0.0;
     }
   }
 
-  HGP_STAMP_DECL
+  HGP_ACC(6);   // prologue: loads, E / K** build, masks (stamps build only)
   const int Kg = a.kend - a.kbeg;
   for (int ch = 0; ch < Kg; ch += PAIRS_DCOLS) {
   // d = y - E^T a'  (a' = c K~^{-1} mean) for the clusters ch .. ch + 15 of the group at once, on the matrix core: column c of
@@ -557,11 +588,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) kt[r] = cc * E[(16 * ((I + NH) % NB) + (ln >> 4) + 4 * r) * TP + 16 * J + (ln & 15)];
               } else {
+                double hk[4], ev[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
-                  kt[r] = (0.5 * (u * u) < PAIRS_CUT) ? cc * HGP_EXPF(-0.5 * (u * u)) : 0.0;
+                  hk[r] = 0.5 * (u * u);
                 }
+                HGP_EXP4(hk, ev);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kt[r] = (hk[r] < PAIRS_CUT) ? cc * ev[r] : 0.0;
               }
             }
             if (I == J) {   // exact diagonal of the one-argument kernel call; identity on the padding
@@ -632,7 +667,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   }   // chunks of PAIRS_DCOLS clusters
 #ifdef HGP_STAMPS
   if ((tid & 63) == 0 && a.stamps)
-    for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
+    for (int i = 0; i < 12; ++i) atomicAdd(&a.stamps[i], hgp_acc_[i]);
 #endif
   if constexpr (!BAND) {   // the last LISTED workgroup to finish hands the list back empty; an unlisted one that reads the count after that
                            // sees 0 and leaves as it would have before
@@ -797,11 +832,15 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
     const int kj = __builtin_amdgcn_readfirstlane(slotblk[slot]);
     const int Kt = kj >> 8, Jb = kj & 255;
     double* dst = (slot < CAP) ? Ec + slot * 256 : Eov + (size_t)(slot - CAP) * 256;
+    double hk[4], ev[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const double u = xbs[16 * Kt + 4 * s + g] - xs[16 * Jb + c];
-      dst[s * 64 + lane] = exp(-0.5 * (u * u));
+      hk[s] = 0.5 * (u * u);
     }
+    exp_neg4(hk, ev);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dst[s * 64 + lane] = (hk[s] < PAIRS_CUT) ? ev[s] : 0.0;
   }
   __syncthreads();
   // E[16 Kt + 4 s + g][16 Jb + c] of the block in `slot`: the B operand of sweep 1 (k-step s) and the A operand of sweep 2
@@ -888,11 +927,15 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
       d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
       if (I <= J) {
         if (kmJ & (1 << I)) {
+          double hk[4], ev[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const double u = xs[16 * I + (ln >> 4) + 4 * r] - xs[16 * J + (ln & 15)];
-            kt[r] = cc * exp(-0.5 * (u * u));
+            hk[r] = 0.5 * (u * u);
           }
+          exp_neg4(hk, ev);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) kt[r] = (hk[r] < PAIRS_CUT) ? cc * ev[r] : 0.0;
         }
         if (I == J) {   // exact diagonal; identity on the padding
 #pragma unroll

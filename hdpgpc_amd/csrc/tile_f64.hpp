@@ -20,7 +20,7 @@
 
 // Diagnostic build only (make stamps): per-phase cycle sums with s_memtime; no stamp executes in the product build.
 #ifdef HGP_STAMPS
-#define HGP_STAMP_DECL unsigned long long hgp_t_, hgp_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define HGP_STAMP_DECL unsigned long long hgp_t_, hgp_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define HGP_T0() hgp_t_ = __builtin_readcyclecounter()
 #define HGP_ACC(i) do { unsigned long long n_ = __builtin_readcyclecounter(); hgp_acc_[i] += n_ - hgp_t_; hgp_t_ = n_; } while (0)
 #else
@@ -137,6 +137,37 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   const double y = __builtin_amdgcn_rsq(a);
   const double e = fma(-(0.5 * a * y), y, 0.5);
   return fma(y * e, fma(1.5, e, 1.0), y);
+}
+
+// exp(-h) for four independent arguments h >= 0 at once (the RBF entries of E and K**).  The library exp() is one long dependent
+// chain: ~650 cycles per call at one wave per SIMD, and the 37 calls per wave of the k_pairs prologue were 24 k of its 31 k cycles
+// (in-kernel stamps).  Here: n = rint(-h log2 e), r = -h - n ln 2 (two-term Cody-Waite, n ln2_hi exact for |n| < 2^11), a degree-13
+// Taylor polynomial of e^r on |r| <= 0.347 (truncation 4e-18, Horner), v_ldexp_f64; the four chains are interleaved instruction
+// by instruction, so the FMAs issue back to back (~100 cycles per value).  Relative error <= 2.3e-16 against exp() over h in
+// [0, 700] (tests/test_gpu_parity.py); arguments beyond 800 (the padding sentinels) return 0.
+__device__ __forceinline__ void exp_neg4(const double (&h)[4], double (&o)[4]) {
+  double n[4], r[4], p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double t = -fmin(h[i], 800.0);
+    n[i] = __builtin_rint(t * 1.4426950408889634);
+    r[i] = fma(n[i], -6.93147180369123816490e-01, t);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[i] = fma(n[i], -1.90821492927058770002e-10, r[i]);
+    p[i] = 1.6059043836821613e-10;   // 1/13!
+  }
+  constexpr double ck[13] = {1.0, 1.0, 0.5, 1.6666666666666666e-01, 4.1666666666666664e-02, 8.3333333333333332e-03,
+                             1.3888888888888889e-03, 1.9841269841269841e-04, 2.4801587301587302e-05, 2.7557319223985893e-06,
+                             2.7557319223985888e-07, 2.5052108385441720e-08, 2.0876756987868100e-09};   // 1/k!, k = 0 .. 12
+#pragma unroll
+  for (int k = 12; k >= 0; --k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = fma(p[i], r[i], ck[k]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_ldexp(p[i], (int)n[i]);
 }
 
 // log-determinant accumulator (product of pivots kept as mantissa * 2^ex) + LAPACK-style info

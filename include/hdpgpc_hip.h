@@ -38,6 +38,10 @@ int hgp_abi_version(void);
  * and accumulator lane maps the kernels assume (tests/test_gpu_parity.py checks it with asymmetric data). */
 int hgp_debug_mfma_f64(const double* A, const double* B, double* C, void* stream);
 
+/* diagnostics: out[i] = exp(-h[i]) through the kernels' own exponential (exp_neg4, tile_f64.hpp: the RBF entries of the
+ * per-pair kernels' E and K** are built with it); n a multiple of 4, h >= 0 (tests/test_gpu_parity.py: <= 3e-16 relative). */
+int hgp_debug_exp_neg_f64(const double* h, int n, double* out, void* stream);
+
 /* a1 - (ConstantKernel(c) * RBF(ell) + WhiteKernel(noise))(X, Y)   [scikit-learn kernels.py; built at
  * GPI_HDP.py:164-166, called at GPI.py:54-58,124,126,474-476].  y == NULL is the one-argument call
  * (white noise on the diagonal, exact c on the diagonal); otherwise no white noise.  K_out: [nx, ny]. */

@@ -41,6 +41,23 @@ def test_mfma_lane_maps():
     assert np.array_equal(dC.cpu().numpy(), A @ B)
 
 
+def test_exp_neg4_against_libm():
+    """The per-pair kernels build E and K** with their own exp(-h) (tile_f64.hpp, exp_neg4): held to the platform's exp()."""
+    rng = np.random.default_rng(1)
+    h = np.concatenate([rng.uniform(0.0, 60.0, 40000), rng.uniform(0.0, 1e-3, 2000), rng.uniform(60.0, 700.0, 2000),
+                        np.array([0.0, 0.6931471805599453, 55.45177444479562, 82.9, 745.0, 799.0, 801.0, 1e300])])
+    dh = dev(h)
+    out = torch.empty_like(dh)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _ffi.lib.hgp_debug_exp_neg_f64(ctypes.c_void_p(dh.data_ptr()), h.size, ctypes.c_void_p(out.data_ptr()), s) == 0
+    got, ref = out.cpu().numpy(), np.exp(-h)
+    normal = ref > 1e-300
+    rel = np.abs(got[normal] - ref[normal]) / ref[normal]
+    assert rel.max() <= 4e-16, rel.max()
+    assert np.all(got[~normal] <= 1e-300) and np.all(got[~normal] >= 0.0)
+    assert got[h.size - 8] == 1.0
+
+
 def test_gram_a1():
     g = golden("gram.npz")
     for i in range(int(g["n_cases"])):

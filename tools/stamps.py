@@ -19,11 +19,13 @@ for (N, K, T) in [(2048, 8, 128), (2048, 8, 96)]:
     plan.loglik(x, y); torch.cuda.synchronize()
     ffi.lib.hgp_debug_stamps(buf)
     v = np.array(list(buf), dtype=np.float64) / (N * K)
-    names = ["d=y-E^T a'", "sweep1 (M'E)", "K** init", "sweep2 (E^T B)", "regularise", "factor+solve", "-", "  of which diag16"]
+    names = ["d=y-E^T a'", "sweep1 (M'E)", "K** init", "sweep2 (E^T B)", "regularise", "factor+solve", "prologue (x4 waves / K pairs)", "  of which diag16"]
     print(f"T={T}: cycles per pair (s_memtime ticks, 100 MHz-independent shader clock)")
     for nme, val in zip(names, v):
         print(f"   {nme:18s} {val:10.0f}")
     print(f"   total              {v[:6].sum():10.0f}")
+    print("   prologue, cumulative per WORKGROUP (cycles): loads+barrier %.0f | + E build, K** tests, barrier %.0f | + band check %.0f | + K** cache = all %.0f"
+          % tuple(v[[8, 9, 10, 6]] * K / 4))
 
 # cooperative kernel (one workgroup per pair), last wave's view
 for (N, K, T) in [(256, 16, 256), (256, 16, 192)]:
