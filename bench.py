@@ -299,7 +299,7 @@ def main():
     from hdpgpc_amd import batch, ops
 
     if world == 1:   # configs[1]
-        n_seg, k_cl, t_len, kern = N_SEG, K_CL, T_LEN, "k_pairs<8>"
+        n_seg, k_cl, t_len, kern = N_SEG, K_CL, T_LEN, "k_pairs<8, true>"
         name = "BASELINE configs[1]: synthetic 2048 segments x 8 clusters, T=128, fp64, irregular segment grids"
     else:            # configs[3], strong scaling: the whole batch is fixed, rank r scores rows [r N/G, (r+1) N/G)
         n_seg, k_cl, t_len, kern = 32768, 16, 256, "k_pairs_cooph<16>"

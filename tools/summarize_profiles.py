@@ -22,7 +22,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             per[(r["Dispatch_Id"], r["Kernel_Name"], r["Counter_Name"])] += float(r["Counter_Value"])
         for (did, k, c), v in per.items():
             pmc[k][c].append(v)
-short = lambda k: (re.search(r"(k_\w+(<\d+>)?)", k) or re.search(r"(\w+)", k)).group(1)
+short = lambda k: (re.search(r"(k_\w+(<[^>]*>)?)", k) or re.search(r"(\w+)", k)).group(1)
 res["pmc_mean_per_dispatch"] = {short(k): {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": max(len(v) for v in cs.values())}
                                 for k, cs in pmc.items() if "hgp" in k or "k_" in k}
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
