@@ -830,7 +830,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
   __syncthreads();
   for (int slot = wave; slot < nslot; slot += NW) {
     const int kj = __builtin_amdgcn_readfirstlane(slotblk[slot]);
-    const int Kt = kj >> 8, Jb = kj & 255;
+    const int Kt = (kj >> 8) & 255, Jb = kj & 255;
     double* dst = (slot < CAP) ? Ec + slot * 256 : Eov + (size_t)(slot - CAP) * 256;
     double hk[4], ev[4];
 #pragma unroll
@@ -839,8 +839,13 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
       hk[s] = 0.5 * (u * u);
     }
     exp_neg4(hk, ev);
+    int ks = 0;   // k-steps of the block with an entry above the cut-off (the others are exact zeros: the sweeps skip their MFMAs)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) dst[s * 64 + lane] = (hk[s] < PAIRS_CUT) ? ev[s] : 0.0;
+    for (int s = 0; s < 4; ++s) {
+      dst[s * 64 + lane] = (hk[s] < PAIRS_CUT) ? ev[s] : 0.0;
+      if (__any(hk[s] < PAIRS_CUT)) ks |= 1 << s;
+    }
+    if (lane == 0) slotblk[slot] = kj | (ks << 16);
   }
   __syncthreads();
   // E[16 Kt + 4 s + g][16 Jb + c] of the block in `slot`: the B operand of sweep 1 (k-step s) and the A operand of sweep 2
@@ -957,7 +962,9 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
       for (int i = 0; i < CH; ++i) BJ[i] = (d4){0.0, 0.0, 0.0, 0.0};
       const double* Mh = Mk + (size_t)g * TP + 16 * CH * h + c;
       double ra[2][4][CH], re[2][4];
+      int ksv[2] = {0, 0};   // live k-steps of the block in each buffer (uniform)
 #define HGP_CFILL(buf, Kt_, slot_)                                                                  \
+  ksv[buf] = __builtin_amdgcn_readfirstlane(slotblk[(slot_)]) >> 16;                                \
   _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
     const double* row_ = Mh + (size_t)(16 * (Kt_) + 4 * s_) * TP;                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) ra[buf][s_][i_] = row_[16 * i_];               \
@@ -965,8 +972,10 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
   }
 #define HGP_CMMA(buf)                                                                               \
   _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_)                                               \
-      if (nb4 & (1 << i_)) BJ[i_] = mfma(ra[buf][s_][i_], re[buf][s_], BJ[i_]);                     \
+    if (ksv[buf] & (1 << s_)) {                                                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_)                                             \
+        if (nb4 & (1 << i_)) BJ[i_] = mfma(ra[buf][s_][i_], re[buf][s_], BJ[i_]);                   \
+    }                                                                                               \
   }
       int m = mJ, slot = bJ;
       int kA = -1, kB = -1;
@@ -1005,10 +1014,13 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
         if (I <= J && m4) {
           const int below = __popc(msk[I] & ((1 << (CH * h)) - 1));
           double af[CH][4];
+          int ks2[CH];
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
+            ks2[i] = 0;
             if (m4 & (1 << i)) {
               const int slot2 = bas[I] + below + __popc(m4 & ((1 << i) - 1));
+              ks2[i] = slotblk[slot2];
 #pragma unroll
               for (int s = 0; s < 4; ++s) af[i][s] = e_op(slot2, s);
             }
@@ -1016,8 +1028,10 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
             if (m4 & (1 << i)) {
+              const int ks = __builtin_amdgcn_readfirstlane(ks2[i]) >> 16;
 #pragma unroll
-              for (int s = 0; s < 4; ++s) U[q == 0 ? H::slotA(I) : H::slotB(I)] = mfma(af[i][s], BJ[i][s], U[q == 0 ? H::slotA(I) : H::slotB(I)]);
+              for (int s = 0; s < 4; ++s)
+                if (ks & (1 << s)) U[q == 0 ? H::slotA(I) : H::slotB(I)] = mfma(af[i][s], BJ[i][s], U[q == 0 ? H::slotA(I) : H::slotB(I)]);
             }
           }
         }
