@@ -253,6 +253,20 @@ def secondary_matrix_terms(dev, ops, b=16384, T=90, reps=5):
     ms9 = timed(lambda: ops.mniw_loglik(M, Gam, m0, None, sc, scale_is_diagonal=True))
     gb8 = b * (3.0 * T * T + 2 * T) * 8 / (ms8 * 1e-3) / 1e9
     gb9 = b * 2.0 * T * T * 8 / (ms9 * 1e-3) / 1e9
+    if T > 128:
+        # the compositions at these sizes are bound by the matrix core, not by HBM (a8: potrf T^3/3 + L^-1 T^3/3 + Z A T^3 +
+        # (Z A) P 2 T^3 = 11/3 T^3 flops for 3 T^2 doubles: 39 flop/byte at T = 256 against a ridge of 9.8); a9 with the diagonal
+        # prior scale: 5/3 T^3.  At 100 % of the fp64 MFMA peak a8 would reach 1.28 M evals/s at T = 256, a9 2.8 M.
+        tf8 = b * (11.0 / 3.0) * T ** 3 / (ms8 * 1e-3) / 1e12
+        tf9 = b * (5.0 / 3.0) * T ** 3 / (ms9 * 1e-3) / 1e12
+        return {"workload": f"{b} items, T={T}: a8 / a9 as compositions (cooperative Cholesky, L^-1 by block columns from L (k_trtri), "
+                            "triangular products, column norms for the diagonal prior scale)",
+                "a8": {"value": b / (ms8 * 1e-3), "unit": "evals/s", "kernel_ms": ms8,
+                       "roofline": {"bound": "mfma", "achieved": tf8, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": tf8 / FP64_MFMA_PEAK_TFLOPS, "flops_per_eval": (11.0 / 3.0) * T ** 3, "hbm_GBps": gb8}},
+                "a9": {"value": b / (ms9 * 1e-3), "unit": "evals/s", "kernel_ms": ms9,
+                       "roofline": {"bound": "mfma", "achieved": tf9, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": tf9 / FP64_MFMA_PEAK_TFLOPS, "flops_per_eval": (5.0 / 3.0) * T ** 3, "hbm_GBps": gb9}}}
     return {"workload": f"{b} items, T={T}: a8 hgp_lat_error_f64 (k_wave_lat_gram), a9 hgp_mniw_loglik_f64 (k_wave_mniw, diagonal prior scale)",
             "a8": {"value": b / (ms8 * 1e-3), "unit": "evals/s", "kernel_ms": ms8,
                    "roofline": {"bound": "hbm", "achieved": gb8, "peak": 8000.0, "unit": "GB/s", "frac": gb8 / 8000.0}},
