@@ -42,6 +42,7 @@ def _load():
         "hgp_pairs_plan_update": (i32, [vp, vp, vp, vp, vp, vp]),
         "hgp_pairs_plan_scalars": (vp, [vp]),
         "hgp_pairs_plan_set_accuracy": (i32, [vp, f64]),
+        "hgp_pairs_plan_set_score_output": (i32, [vp, i32]),
         "hgp_loglik_pairs_f64": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
         "hgp_gemm_batched_f64": (i32, [i32, i32, i32, i32, i32, f64, vp, i32, i64, vp, i32, i64, f64, vp, i32, i64, i32, vp]),
         "hgp_matrix_lik_ws_bytes": (sz, [i32, i32]),

@@ -116,11 +116,11 @@ def emission_scores(plan, x, y, first_noise=None, group=None, events=None, want_
         fnl = None if first_noise is None else first_noise[lo:hi].contiguous()
         if events is not None:
             events[0].record()
-        quad, _, info = plan.loglik(xs.contiguous(), ys.contiguous(), first_noise=fnl, want_logdet=False)
+        q, _, info = plan.loglik(xs.contiguous(), ys.contiguous(), first_noise=fnl, want_logdet=False, score=True)
         if events is not None:                   # the bracket holds the pair kernels only
             events[1].record()
         infos.append(info)
-        return -0.5 * quad - 0.5 * xs.shape[1] * LOG2PI      # GPI_model.py:285 (no log-determinant)
+        return q                                 # GPI_model.py:285 (no log-determinant), written by the kernels
 
     q = sharded_scores(fn, x, y, group)
     return (q, infos[0]) if want_info else q

@@ -65,6 +65,7 @@ struct hgp_pairs_plan {
   int32_t* d_acc_list = nullptr;   // [1 + K]: number of flagged clusters, then their ids
   double* d_sscr = nullptr;     // [acc_grid][NB*NB][64][4]: per-workgroup storage of S = K~^{-1} K*
   int32_t* d_fb = nullptr;      // [PAIRS_FB_CAP + 2]: fall-back list of k_pairs (see PairsArgs::fb); zero between launches
+  int score_out = 0;            // hgp_pairs_plan_set_score_output: out_quad receives -0.5 quad - 0.5 Ts log(2 pi)
 };
 
 // hgp_pairs_acc.hip
@@ -107,6 +108,8 @@ struct PairsArgs {
   int nscr;
   long escr_stride;
   int flags;             // bit 0: generic (mask-driven) sweeps even for a block-tridiagonal E (HGP_PAIRS_GENERIC=1: A/B runs and tests)
+  double score_add;      // score output (hgp_pairs_plan_set_score_output): out_quad = score_on ? -0.5 quad + score_add : quad
+  int score_on;
   int32_t* fb;           // k_pairs: fall-back list [0] = count, [1 .. PAIRS_FB_CAP] = segments, [1 + PAIRS_FB_CAP] = finished workgroups
 };
 

@@ -1813,6 +1813,12 @@ int hgp_pairs_plan_set_accuracy(hgp_pairs_plan* p, double tol) {
   return 0;
 }
 
+int hgp_pairs_plan_set_score_output(hgp_pairs_plan* p, int on) {
+  if (!p) return -1;
+  p->score_out = on ? 1 : 0;
+  return 0;
+}
+
 int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double* y, int N, int Ts,
                          const double* first_noise, const int32_t* sel, double* out_quad, double* out_logdet,
                          int32_t* out_info, void* stream) {
@@ -1834,7 +1840,7 @@ int hgp_loglik_pairs_f64(const hgp_pairs_plan* p, const double* x, const double*
                 hgp_internal_stamp_dev,
 #endif
                 p->K, out_quad, out_logdet, out_info, p->d_escr, p->d_eflags, p->nscr, p->escr_stride,
-                env_on("HGP_PAIRS_GENERIC") ? 1 : 0, p->d_fb};
+                env_on("HGP_PAIRS_GENERIC") ? 1 : 0, -0.5 * (double)Ts * 1.8378770664093453, p->score_out, p->d_fb};
     rc = hgp_internal_pairs_fast(a, p->NB, p->coop, st);
   }
   if (rc == 0) rc = hgp_internal_pairs_acc(p, x, y, N, Ts, first_noise, sel, out_quad, out_logdet, out_info, st);

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
       double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
       double q = wave_sum(dsq) / v2;
       if (lane == 0) {
-        a.out_quad[oidx] = q;
+        a.out_quad[oidx] = a.score_on ? fma(-0.5, q, a.score_add) : (q);
         if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
         if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
       }
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     const double q = wave_factor<NB, 2, (NB >= 8) && !HGP_PAIRS_DIAG_MFMA>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
 #endif
     if (lane == 0) {
-      a.out_quad[oidx] = q;
+      a.out_quad[oidx] = a.score_on ? fma(-0.5, q, a.score_add) : (q);
       if (a.out_logdet) a.out_logdet[oidx] = pa.logdet();
       if (a.out_info) a.out_info[oidx] = pa.info;
     }
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
       const double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
       double tot_ = 0.0;
       for (int w_ = 0; w_ < NW; ++w_) tot_ += red[w_];
-      a.out_quad[oidx] = tot_ / v2;
+      a.out_quad[oidx] = a.score_on ? fma(-0.5, tot_ / v2, a.score_add) : (tot_ / v2);
       if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
       if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
     }
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
   if (tid == 0) {
     double tot_ = 0.0;
     for (int w_ = 0; w_ < NW; ++w_) tot_ += red[8 + w_];
-    a.out_quad[oidx] = tot_;
+    a.out_quad[oidx] = a.score_on ? fma(-0.5, tot_, a.score_add) : (tot_);
     if (a.out_logdet) a.out_logdet[oidx] = ld;
     if (a.out_info) a.out_info[oidx] = info;
   }

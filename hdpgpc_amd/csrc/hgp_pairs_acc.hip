@@ -185,6 +185,8 @@ struct AccArgs {
   double* out_logdet;
   int32_t* out_info;
   double* sscr;
+  double score_add;   // out_quad = score_on ? -0.5 quad + score_add : quad (hgp_pairs_plan_set_score_output)
+  int score_on;
 };
 
 template <int NB>
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
         const double v2 = v + 1e-8 * fmax(fabs(v), F64_EPS);
         double tot_ = 0.0;
         for (int w_ = 0; w_ < NW; ++w_) tot_ += red[w_];
-        a.out_quad[oidx] = tot_ / v2;
+        a.out_quad[oidx] = a.score_on ? fma(-0.5, tot_ / v2, a.score_add) : (tot_ / v2);
         if (a.out_logdet) a.out_logdet[oidx] = (double)Ts * log(v2);
         if (a.out_info) a.out_info[oidx] = (v2 > 0.0) ? 0 : 1;
       }
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
     if (tid == 0) {
       double tot_ = 0.0;
       for (int w_ = 0; w_ < NW; ++w_) tot_ += red[8 + w_];
-      a.out_quad[oidx] = tot_;
+      a.out_quad[oidx] = a.score_on ? fma(-0.5, tot_, a.score_add) : (tot_);
       if (a.out_logdet) a.out_logdet[oidx] = ld;
       if (a.out_info) a.out_info[oidx] = info;
     }
@@ -462,7 +464,7 @@ int hgp_internal_pairs_acc(const hgp_pairs_plan* p, const double* x, const doubl
                            const int32_t* sel, double* out_quad, double* out_logdet, int32_t* out_info, hipStream_t st) {
   if (p->acc_tol < 0.0) return 0;
   AccArgs a{x, y, N, Ts, p->d_xb, p->T, p->d_scal, p->d_mu, p->d_Lop, p->d_LTop, p->d_Dop, p->d_Sop, p->d_acc_list,
-            first_noise, sel, p->K, out_quad, out_logdet, out_info, p->d_sscr};
+            first_noise, sel, p->K, out_quad, out_logdet, out_info, p->d_sscr, -0.5 * (double)Ts * 1.8378770664093453, p->score_out};
   switch (p->NB) {
     case 2: return launch_pairs_acc<2>(a, st);
     case 4: return launch_pairs_acc<4>(a, st);

@@ -182,6 +182,7 @@ class PairsPlan:
             raise ValueError("bad plan shape")
         self._buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self._h = ctypes.c_void_p()
+        self._score_out = False
         _ffi.check(_ffi.lib.hgp_pairs_plan_create(ctypes.byref(self._h), self.T, self.Ts_max, self.K,
                                                   theta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                                   _ptr(self._buf), nbytes), "pairs_plan_create")
@@ -221,10 +222,13 @@ class PairsPlan:
         """Boolean [K] (host sync): clusters the last update() routed to the solve-based kernel."""
         return self.scalars()[:, 7].cpu().numpy() != 0.0
 
-    def loglik(self, x, y, first_noise=None, want_logdet=True, want_info=True, sel=None):
+    def loglik(self, x, y, first_noise=None, want_logdet=True, want_info=True, sel=None, score=False):
         """x, y [N,Ts] -> (quad [N,K], logdet [N,K] or None, info [N,K] or None).
 
-        sel [N] int32 (optional): segment n is scored against cluster sel[n] only; outputs (and first_noise) are [N]."""
+        sel [N] int32 (optional): segment n is scored against cluster sel[n] only; outputs (and first_noise) are [N].
+        score=True: the first output is the reference's score -0.5 quad - 0.5 Ts log(2 pi) (GPI_model.py:285), written by the
+        kernels themselves (hgp_pairs_plan_set_score_output) - no arithmetic launch behind the pair kernels.
+        Every output element is written by exactly one pair kernel: the buffers are not cleared first."""
         x = _dev64(x, "x")
         y = _dev64(y, "y")
         N, Ts = x.shape
@@ -234,17 +238,20 @@ class PairsPlan:
             sel = torch.as_tensor(sel, device=dev).to(torch.int32).contiguous()
         if first_noise is not None:
             first_noise = _dev64(first_noise.reshape(shape), "first_noise")
-        quad = torch.zeros(shape, dtype=torch.float64, device=dev)
-        logdet = torch.zeros(shape, dtype=torch.float64, device=dev) if want_logdet else None
-        info = torch.zeros(shape, dtype=torch.int32, device=dev) if want_info else None
+        quad = torch.empty(shape, dtype=torch.float64, device=dev)
+        logdet = torch.empty(shape, dtype=torch.float64, device=dev) if want_logdet else None
+        info = torch.empty(shape, dtype=torch.int32, device=dev) if want_info else None
+        if bool(score) != self._score_out:
+            _ffi.check(_ffi.lib.hgp_pairs_plan_set_score_output(self._h, int(bool(score))), "pairs_plan_set_score_output")
+            self._score_out = bool(score)
         _ffi.check(_ffi.lib.hgp_loglik_pairs_f64(self._h, _ptr(x), _ptr(y), N, Ts, _ptr(first_noise), _ptr(sel), _ptr(quad),
                                                  _ptr(logdet), _ptr(info), _stream()), "loglik_pairs")
         return quad, logdet, info
 
     def score(self, x, y, first_noise=None, sel=None):
         """The reference's score: -0.5 quad - 0.5 Ts log(2 pi)  (GPI_model.py:285, no log-determinant)."""
-        quad, _, info = self.loglik(x, y, first_noise, want_logdet=False, sel=sel)
-        return -0.5 * quad - 0.5 * x.shape[1] * LOG2PI, info
+        q, _, info = self.loglik(x, y, first_noise, want_logdet=False, sel=sel, score=True)
+        return q, info
 
     def close(self):
         if self._h:

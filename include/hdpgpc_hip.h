@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HGP_ABI_VERSION 4   /* 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path), assignment tail, warp fit, member-step lists; 4: + batched chain gather / finish */
+#define HGP_ABI_VERSION 5   /* 5: + hgp_pairs_plan_set_score_output, hgp_debug_exp_neg_f64; 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path), assignment tail, warp fit, member-step lists; 4: + batched chain gather / finish */
 /* largest T (basis length) and T* (segment length) served by the register-resident wave kernels */
 #define HGP_MAX_T_WAVE 128
 /* largest T served at all: 128 < T <= 256 runs on cooperative kernels (one workgroup of 4-8 waves per matrix / pair) */
@@ -123,6 +123,10 @@ const double* hgp_pairs_plan_scalars(const hgp_pairs_plan* plan);
  *   tol == 0: every cluster;   tol < 0: none (explicit operator everywhere).
  * Takes effect at the next hgp_pairs_plan_update. */
 int hgp_pairs_plan_set_accuracy(hgp_pairs_plan* plan, double tol);
+/* What hgp_loglik_pairs_f64 stores in out_quad:  on == 0 (default): d^T cov^{-1} d;  on != 0: the reference's score itself,
+ * -0.5 d^T cov^{-1} d - 0.5 Ts log(2 pi)  (GPI_model.py:285, no log-determinant) - written by the pair kernels, so that the caller
+ * needs no arithmetic of its own behind the launch.  Takes effect at the next hgp_loglik_pairs_f64. */
+int hgp_pairs_plan_set_score_output(hgp_pairs_plan* plan, int on);
 /* x[N,Ts], y[N,Ts]: segment grids and values.  first_noise[N,K] (may be NULL): additive diagonal of the
  * `first` branch (GPI_model.py:271-273).  Outputs [N,K]: out_quad = d^T cov^{-1} d, out_logdet (may be NULL),
  * out_info (may be NULL).  cov carries the reference's regularisation: +1e-6 I (GPI.py:501, dense Sigma only),

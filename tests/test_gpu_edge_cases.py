@@ -284,3 +284,28 @@ def test_static_band_sweeps_equal_the_mask_driven_ones_bit_for_bit(T, Ts, monkey
         for k in (0, K - 1):
             _, qq, ll = orc.log_sq_error_state(x[n], y[n], b["xb"], b["mean"][k], b["Sigma"][k], tuple(b["theta"][k]), float(fn[n, k]))
             assert abs(float(q1[n, k]) - qq) <= 1e-8 * abs(qq) and abs(float(l1[n, k]) - ll) <= 1e-8 * abs(ll)
+
+
+def test_score_output_written_by_the_kernels():
+    """hgp_pairs_plan_set_score_output: out_quad receives -0.5 quad - 0.5 Ts log(2 pi) (GPI_model.py:285) from the pair kernels
+    themselves - fast, cooperative (T > 128) and solve-based clusters, with and without a per-segment selection; the uncleared
+    output buffers are written everywhere."""
+    import math
+    for (N, K, T, ells) in [(96, 4, 90, (1.2, 1.2, 3.0, 1.2)), (40, 3, 144, (1.2, 3.0, 1.2))]:
+        b = orc.synthetic_batch(N, K, T, seed=11)
+        theta = b["theta"].copy()
+        theta[:, 1] = ells
+        plan = ops.PairsPlan(T, T, theta).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+        x, y = dev(b["x"]), dev(b["y"])
+        quad, _, info = plan.loglik(x, y, want_logdet=False)
+        sc, _, info2 = plan.loglik(x, y, want_logdet=False, score=True)
+        ref = -0.5 * quad - 0.5 * T * math.log(2.0 * math.pi)
+        assert int(info.abs().max()) == 0 and torch.equal(info, info2)
+        assert torch.allclose(sc, ref, rtol=1e-15, atol=0.0)
+        s2, _ = plan.score(x, y)
+        assert torch.equal(s2, sc)
+        sel = torch.arange(N, device="cuda", dtype=torch.int32) % K
+        q1, _, _ = plan.loglik(x, y, want_logdet=False, sel=sel)
+        s1, _, _ = plan.loglik(x, y, want_logdet=False, sel=sel, score=True)
+        assert torch.allclose(s1, -0.5 * q1 - 0.5 * T * math.log(2.0 * math.pi), rtol=1e-15, atol=0.0)
+        assert torch.equal(q1, quad[torch.arange(N, device="cuda"), sel.long()])
