@@ -650,12 +650,71 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm(GemmArgs a) {
   }
 }
 
+// Large products (M, N, Kd multiples of 32, Kd > 128, no transposes: the a8 / a9 compositions at 128 < T <= 256): one wave per
+// 32 x 32 block of C - four accumulator tiles fed by two A and two B fragments per k-step, i.e. half the L2 operand traffic per
+// MFMA of k_gemm (which is bound by exactly that traffic at these sizes: 14 TFLOP/s on the 2 T^3 product at T = 256).
+__global__ __launch_bounds__(64 * WAVES) void k_gemm22(GemmArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int ntn = a.N / 32, ntm = a.M / 32;
+  const int tile = blockIdx.x * WAVES + wave;
+  if (tile >= ntm * ntn) return;
+  const int ti = tile / ntn, tj = tile % ntn;
+  const int by = (int)blockIdx.y + a.boff;
+  const int b1 = by / a.nb2, b2 = by % a.nb2;
+  const double* A = a.A + (size_t)b1 * a.sA + (size_t)b2 * a.sA2 + (size_t)(32 * ti + c) * a.lda + g;
+  const double* B = a.B + (size_t)b1 * a.sB + (size_t)b2 * a.sB2 + (size_t)g * a.ldb + 32 * tj + c;
+  double* C = a.C + (size_t)b1 * a.sC + (size_t)b2 * a.sC2;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  int nk = a.Kd / 4;
+  if (a.triA) nk = min(nk, 8 * (ti + 1));   // lower-triangular A: rows 32 ti .. 32 ti + 31 only reach k < 32 (ti + 1)
+  constexpr int TR = 8;                      // k-steps per trip (Kd is a multiple of 32 here)
+  for (int k0 = 0; k0 < nk; k0 += TR) {
+    double av[TR][2], bv[TR][2];
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      const size_t k = 4 * (size_t)(k0 + u);
+      av[u][0] = A[k];
+      av[u][1] = A[k + 16 * (size_t)a.lda];
+      bv[u][0] = B[k * a.ldb];
+      bv[u][1] = B[k * a.ldb + 16];
+    }
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma(av[u][i], bv[u][j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * ti + 16 * i + g + 4 * r, col = 32 * tj + 16 * j + c;
+        double v = a.alpha * acc[i][j][r];
+        if (a.beta != 0.0) v += a.beta * (a.D ? a.D[(size_t)b1 * a.sD + (size_t)row * a.ldd + col] : C[(size_t)row * a.ldc + col]);
+        C[(size_t)row * a.ldc + col] = v;
+      }
+}
+
 int launch_gemm(const GemmArgs& a0, int batch, hipStream_t st) {
   const int nt = ((a0.M + 15) / 16) * ((a0.N + 15) / 16);
   for (int b0 = 0; b0 < batch; b0 += 65535) {   // gridDim.y <= 65535
     GemmArgs a = a0;
     a.boff = b0;
     const int nb = std::min(65535, batch - b0);
+    if (!a.tA && !a.tB && a.M % 32 == 0 && a.N % 32 == 0 && a.Kd % 32 == 0 && a.Kd > 128 && !env_on("HGP_GEMM_PLAIN")) {
+      const int nt2 = (a.M / 32) * (a.N / 32);
+      hipLaunchKernelGGL(k_gemm22, dim3((nt2 + WAVES - 1) / WAVES, nb), dim3(64 * WAVES), 0, st, a);
+      continue;
+    }
     if (a.Kd <= 96 && a.Kd > 32)
       hipLaunchKernelGGL(k_gemm<24>, dim3((nt + WAVES - 1) / WAVES, nb), dim3(64 * WAVES), 0, st, a);
     else if (a.Kd <= 128 && a.Kd > 96)
