@@ -774,11 +774,15 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
     const bool real = (b16 < NB) ? (i < T) : (i < Ts);
     const double v = (b16 < NB) ? xbs[i] : xs[i];
     double lo = real ? v : __builtin_inf(), hi = real ? v : -__builtin_inf();
-#pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) {
-      lo = fmin(lo, __shfl_xor(lo, o, 64));
-      hi = fmax(hi, __shfl_xor(hi, o, 64));
-    }
+    // all-reduce over the 16 lanes of a row by DPP rotations (was: four ds_bpermute round trips per value)
+    lo = fmin(lo, dpp_f64<0x128>(lo));
+    hi = fmax(hi, dpp_f64<0x128>(hi));
+    lo = fmin(lo, dpp_f64<0x124>(lo));
+    hi = fmax(hi, dpp_f64<0x124>(hi));
+    lo = fmin(lo, dpp_f64<0x122>(lo));
+    hi = fmax(hi, dpp_f64<0x122>(hi));
+    lo = fmin(lo, dpp_f64<0x121>(lo));
+    hi = fmax(hi, dpp_f64<0x121>(hi));
     if (lane == 0) {
       rng[2 * b16] = lo;
       rng[2 * b16 + 1] = hi;
@@ -800,15 +804,16 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW, (NB <= 8) ? 2 : 1) void k_pairs
     }
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid <= NB) {   // thread J: first slot of column J and the rows of B[:, J] that sweep 2 reads (prefix over the columns before it)
     int s = 0, o = 0;
+#pragma unroll
     for (int J = 0; J < NB; ++J) {
-      base[J] = s;
-      s += __popc(amask[J]);
-      o |= amask[J];
-      pneed[J] = o;
+      const int am = amask[J];
+      if (J < tid) s += __popc(am);
+      if (J <= tid) o |= am;
     }
-    base[NB] = s;
+    base[tid] = s;
+    if (tid < NB) pneed[tid] = o;
   }
   __syncthreads();
   if (actE) slotblk[base[myJb] + __popc(amask[myJb] & ((1 << myKt) - 1))] = (myKt << 8) | myJb;
