@@ -18,10 +18,10 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
 
 
-@pytest.mark.parametrize("N,K,T,n_spot", [(2048, 8, 128, 16), (4096, 16, 256, 4)])
+@pytest.mark.parametrize("N,K,T,n_spot", [(2048, 8, 128, 16), (4096, 16, 256, 4), (32768, 16, 256, 2)])
 def test_full_size_batch_properties(N, K, T, n_spot):
-    """configs[1] (2 048 x 8, T = 128) and the per-GPU shard of configs[3] (4 096 segments x 16 clusters, T = 256) on
-    irregular grids."""
+    """configs[1] (2 048 x 8, T = 128), the per-GPU shard of configs[3] (4 096 segments x 16 clusters, T = 256) and the WHOLE
+    configs[3] batch (32 768 x 16, T = 256: what bench.py --gpus N shards) on irregular grids."""
     b = orc.synthetic_batch(N, K, T, seed=20260703)
     xb, mean, Sig = dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"])
     x, y = dev(b["x"]), dev(b["y"])
