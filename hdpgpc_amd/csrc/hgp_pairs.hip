@@ -47,8 +47,9 @@ constexpr size_t pairs_lds_bytes() {
 //  * no bit scans, no scalar branches, no conditional refills around the operand ring: one flat list of (column, half, k-block,
 //    half-block) items, item t multiplied from ring slot t % 4 and the slot refilled with item t + 4 (exact s_waitcnt counts);
 //  * the K** seeds and sweep 2 of a pass follow its last item with compile-time tile lists.
-// Same operations in the same order per accumulator as the generic sweeps: bit-identical results (HGP_PAIRS_GENERIC=1 runs the
-// generic code for A/B; tests/test_gpu_edge_cases.py compares the two).
+// Same operations in the same order per accumulator as the generic sweeps: bit-identical covariances, factors and
+// log-determinants (HGP_PAIRS_GENERIC=1 runs the generic code for A/B; tests/test_gpu_edge_cases.py compares the two); the
+// quadratic form agrees to rounding (the band kernel defers the cross-row sums of the right-hand side, wave_factor RHS_DEFER).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int NB>
 struct PairsBand {
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
 #pragma unroll
     for (int i_ = 0; i_ < NB * (NB + 1) / 2; ++i_) q += cov[i_][0] + cov[i_][1] + cov[i_][2] + cov[i_][3];
 #else
-    const double q = wave_factor<NB, 2, (NB >= 8) && !HGP_PAIRS_DIAG_MFMA>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
+    const double q = wave_factor<NB, 2, (NB >= 8) && !HGP_PAIRS_DIAG_MFMA, BAND || (NB < 8)>(cov, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, Ts);
 #endif
     if (lane == 0) {
       a.out_quad[oidx] = a.score_on ? fma(-0.5, q, a.score_add) : (q);

@@ -687,11 +687,17 @@ __device__ __forceinline__ d4 diag16_sel(const d4& X, double* scr, int lane, Piv
 // RHSMODE: 0 = none; 1 = one block column of 16 right-hand sides as MFMA tiles R[K]; 2 = ONE right-hand side kept
 // as a vector in LDS (dvec[16 NB], per wave) and eliminated on the VALU next to the MFMA stream: on exit dvec
 // holds z = L^{-1} d and the return value is z^T z (valid in every lane).
-template <int NB, int RHSMODE, bool DIAG_VALU = false>
+template <int NB, int RHSMODE, bool DIAG_VALU = false, bool RHS_DEFER = false>
 __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[NB], double* scr, double* Wlds,
                                               double* dvec, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n) {
   constexpr bool RHS = (RHSMODE == 1);
   double zq = 0.0;
+  // RHSMODE 2: what the steps K' < K have to subtract from d_K is kept per lane as the partial sum over the lane's own rows
+  // (dp[K], lane (g, c): rows g + 4r of the tiles U_K'K) and reduced over the four 16-lane rows ONCE, when block K becomes the
+  // pivot block - one cross-row sum and one LDS update per block instead of one per (K', K) pair (28 -> 8 at NB = 8).
+  double dp[NB];
+#pragma unroll
+  for (int K = 0; K < NB; ++K) dp[K] = 0.0;
 #pragma unroll
   for (int K = 0; K < NB; ++K) {
     const int lane = launder(lane_in);
@@ -703,6 +709,11 @@ __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R
       for (int s = 0; s < 4; ++s) Wlds[(K * 4 + s) * 64 + lane] = W[s];
     }
     if (RHSMODE == 2) {   // z_K = W d_K : lane (g,c) sums W[c][4s+g] d[4s+g] over s, rows are summed over g
+      if (RHS_DEFER && K > 0) {   // d_K -= sum over K' < K of U_K'K^T z_K' (deferred, see above)
+        const double q = xrow_sum(dp[K]);
+        if (g == 0) dvec[16 * K + c] -= q;
+        __builtin_amdgcn_wave_barrier();
+      }
       double p = 0.0;
 #pragma unroll
       for (int s = 0; s < 4; ++s) p = fma(W[s], dvec[16 * K + 4 * s + g], p);
@@ -745,15 +756,23 @@ __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R
       double zr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) zr[r] = dvec[16 * K + g + 4 * r];
+      if (RHS_DEFER) {
 #pragma unroll
-      for (int I = K + 1; I < NB; ++I) {
-        double q = 0.0;
+        for (int I = K + 1; I < NB; ++I) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) q = fma(U[tix(K, I, NB)][r], zr[r], q);
-        q = xrow_sum(q);
-        if (g == 0) dvec[16 * I + c] -= q;
+          for (int r = 0; r < 4; ++r) dp[I] = fma(U[tix(K, I, NB)][r], zr[r], dp[I]);
+        }
+      } else {   // reduced and subtracted at once (the mask-driven k_pairs<8, false> has no registers for the partial sums)
+#pragma unroll
+        for (int I = K + 1; I < NB; ++I) {
+          double q = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q = fma(U[tix(K, I, NB)][r], zr[r], q);
+          q = xrow_sum(q);
+          if (g == 0) dvec[16 * I + c] -= q;
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     }
     // trailing update: A_IJ -= U_KI^T U_KJ  for K < I <= J  (and the rhs tiles I > K).  No look-ahead: on gfx950 the
     // f64 MFMA and f64 VALU share the DP pipe (tools/probe_coexec.hip: 1 MFMA + 12 independent v_fma_f64 = 64 + 64 clk),
