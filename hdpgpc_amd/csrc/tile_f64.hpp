@@ -1503,6 +1503,10 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
   __syncthreads();
   double zq = 0.0;
   const int JA = wave, JB = NB - 1 - wave;   // my block columns
+  // what the steps so far have to subtract from d_JA / d_JB, as per-lane partial sums over the lane's own rows: reduced over the
+  // four 16-lane rows once, when the column becomes the pivot block (do_diag), instead of once per step inside panel_col -
+  // one cross-row sum, one LDS read-modify-write and their latency less on every step of the critical chain
+  double dpA = 0.0, dpB = 0.0;
 #ifdef HGP_STAMPS
   unsigned long long cf_t = __builtin_readcyclecounter();
 #define HGP_DF(i) do { unsigned long long n_ = __builtin_readcyclecounter(); pa.cf[i] += n_ - cf_t; cf_t = n_; } while (0)
@@ -1519,6 +1523,11 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
     const d4 Wd = diag16_sel<false>(U[C::diag_slot(K)], scr, lane, pa, 16 * K, nullptr, 0, n - 16 * K);
 #pragma unroll
     for (int s = 0; s < 4; ++s) Wall[(K * 4 + s) * 64 + lane] = Wd[s];
+    if constexpr (K > 0) {   // d_K -= sum over K' < K of U_K'K^T z_K' (deferred)
+      const double q = xrow_sum((K < C::NW) ? dpA : dpB);
+      if (g == 0) dvec[16 * K + c] -= q;
+      __builtin_amdgcn_wave_barrier();
+    }
     double p = 0.0;   // z_K = W d_K
 #pragma unroll
     for (int s = 0; s < 4; ++s) p = fma(Wd[s], dvec[16 * K + 4 * s + g], p);
@@ -1568,11 +1577,11 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
       for (int s = 0; s < 4; ++s) acc = mfma(W[s], t[s], acc);
       U[sl] = acc;
       lds_tile_store(rb, J, lane, acc);
-      double tq = 0.0;                          // d_J -= U_KJ^T z_K
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tq = fma(acc[r], zr[r], tq);
-      tq = xrow_sum(tq);
-      if (g == 0) dvec[16 * J + c] -= tq;
+      for (int r = 0; r < 4; ++r) {             // d_J -= U_KJ^T z_K (partial sums, see dpA / dpB)
+        if (h == 0) dpA = fma(acc[r], zr[r], dpA);
+        else dpB = fma(acc[r], zr[r], dpB);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane_in == 0) __hip_atomic_store(&rowpub[J], K + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       return acc;
