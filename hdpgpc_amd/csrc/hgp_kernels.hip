@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 6) ? 2 : 1) void k_wave_score1(E
   __builtin_amdgcn_wave_barrier();
   PivotAcc pa;
   pa.init();
-  const double q = wave_factor<NB, 2, (NB >= 8)>(U, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, T);
+  const double q = wave_factor<NB, 2, (NB >= 8), (NB < 8)>(U, Rnone, scr, nullptr, dv, lane, pa, nullptr, 0, T);
   if (lane == 0) {
     a.out_quad[seg] = q;
     if (a.out_logdet) a.out_logdet[seg] = pa.logdet();
