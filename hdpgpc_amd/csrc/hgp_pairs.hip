@@ -124,7 +124,7 @@ struct PairsBand {
 };
 
 template <int NB>
-__device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const double* __restrict__ Mbase, const double* E,
+__device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const double* __restrict__ Mu, const double* E,
                                             int lane_in, double cc, double noise, int Ts
 #ifdef HGP_STAMPS
                                             , unsigned long long& hgp_t_, unsigned long long (&hgp_acc_)[12]
@@ -134,27 +134,31 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
   constexpr int TP = 16 * NB, NH = NB / 2, NI = PB::nitems();
   double ra[4][2][NH], re[4][2];
   d4 BJ[NH];
+  // Every operand address of the sweeps is  (uniform base + compile-time constant) + ONE of two lane offsets: Mu is uniform
+  // (the cluster index comes through v_readfirstlane), so the M' loads take the scalar-base form of global_load and the E reads
+  // an immediate offset - the ~14 VALU instructions of address arithmetic per ring fill (1.5 k per pair) are gone.
+  const unsigned moff0 = (unsigned)((lane_in >> 4) * TP + 2 * (lane_in & 15));   // row g of M', tile-pair interleaved column 2c
+  const unsigned eoff0 = (unsigned)((lane_in >> 4) * TP + (lane_in & 15));       // row g, column c (E, and the odd last tile of M')
   auto fill = [&](auto tc) {
     constexpr int t = decltype(tc)::value;
     constexpr auto it = PB::item(t);
     if constexpr (it.valid) {
       constexpr int slot = t & 3, rm = PB::rows(it.J, it.h);
-      const int lane = launder(lane_in);
-      const int g = lane >> 4, c = lane & 15;
+      const unsigned moff = (unsigned)launder((int)moff0), eoff = (unsigned)launder((int)eoff0);   // opaque per fill: no merging / hoisting of the loads of different fills
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
         if (!PB::alive(it.Lt, it.J, 2 * it.hb + s_)) continue;
-        const double* row_ = Mbase + 16 * NH * it.h + (size_t)(16 * it.Lt + 4 * (2 * it.hb + s_)) * TP;
+        const double* row_ = Mu + 16 * NH * it.h + (size_t)(16 * it.Lt + 4 * (2 * it.hb + s_)) * TP;
 #pragma unroll
         for (int P_ = 0; P_ < NH / 2; ++P_) {
           if ((rm >> (2 * P_)) & 3) {
-            const d2 t_ = *reinterpret_cast<const d2*>(row_ + 32 * P_ + 2 * c);
+            const d2 t_ = *reinterpret_cast<const d2*>(row_ + 32 * P_ + moff);
             ra[slot][s_][2 * P_] = t_[0];
             ra[slot][s_][2 * P_ + 1] = t_[1];
           }
         }
-        if ((NH & 1) && ((rm >> (NH - 1)) & 1)) ra[slot][s_][NH - 1] = row_[16 * (NH - 1) + c];
-        re[slot][s_] = E[(16 * it.Lt + 4 * (2 * it.hb + s_) + g) * TP + 16 * it.J + c];
+        if ((NH & 1) && ((rm >> (NH - 1)) & 1)) ra[slot][s_][NH - 1] = (row_ + 16 * (NH - 1))[eoff];
+        re[slot][s_] = (E + (16 * it.Lt + 4 * (2 * it.hb + s_)) * TP + 16 * it.J)[eoff];
       }
     }
   };
@@ -179,8 +183,8 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
     }
     fill(std::integral_constant<int, t + 4>{});
     if constexpr (it.last) {
-      const int ln = launder(lane_in);
-      const int g = ln >> 4, c = ln & 15;
+      const int g = lane_in >> 4, c = lane_in & 15;
+      const unsigned eoff = (unsigned)launder((int)eoff0);
       HGP_ACC(1);
       constexpr int NG = PB::ngroups(J, h);
       double af[2][4];
@@ -190,7 +194,7 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
           constexpr auto gp = PB::group(J, h, n_);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (PB::alive(NH * h + gp.i, gp.I, r)) af[n_ & 1][r] = E[(16 * (NH * h + gp.i) + 4 * r + g) * TP + 16 * gp.I + c];
+            if (PB::alive(NH * h + gp.i, gp.I, r)) af[n_ & 1][r] = (E + (16 * (NH * h + gp.i) + 4 * r) * TP + 16 * gp.I)[eoff];
         }
       };
       ldaf(std::integral_constant<int, 0>{});
@@ -200,7 +204,7 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
           d4 kt = (d4){0.0, 0.0, 0.0, 0.0};
           if ((PB::kmask(J) >> I) & 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) kt[r] = cc * E[(16 * ((I + NH) % NB) + g + 4 * r) * TP + 16 * J + c];
+            for (int r = 0; r < 4; ++r) kt[r] = cc * (E + (16 * ((I + NH) % NB) + 4 * r) * TP + 16 * J)[eoff];
           }
           if (I == J) {
 #pragma unroll
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
   for (int kk = a.kbeg + ch + wave; kk < kk_end; kk += WAVES) {
     const int lane = launder(tid) & 63;
     const int g = lane >> 4, c = lane & 15;
-    const int kc = a.perm[kk];
+    const int kc = BAND ? __builtin_amdgcn_readfirstlane(a.perm[kk]) : a.perm[kk];   // band kernel: uniform, the per-cluster bases are scalar
     if (a.sel && a.sel[n] != kc) continue;
     HGP_T0();
     const double* sc = a.scal + 8 * kc;
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
     const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP;   // + column offset inside HGP_FILL (interleaved)
 #endif
     if constexpr (BAND) {
-      band_sweeps<NB>(cov, Mbase, E, lane, cc, noise, Ts
+      band_sweeps<NB>(cov, a.Mp + (size_t)kc * TP * TP, E, lane, cc, noise, Ts
 #ifdef HGP_STAMPS
                       , hgp_t_, hgp_acc_
 #endif
