@@ -75,7 +75,12 @@ class OnlineLoop:
     def include_sample(self, x_train, y, with_warp=True, force_model=None, minibatch=0, classify=False):
         """GPI_HDP.py:1906-2208."""
         if with_warp:
-            raise NotImplementedError("include_sample(with_warp=True): the per-beat warp fit is not part of this build")
+            # The reference itself cannot run this path: with one cluster (the second beat of any run) compute_warp_y's greedy
+            # branch takes torch.max of an empty tensor (GPI_HDP.py:3313, liks[:-1] with M = 1) and raises RuntimeError -
+            # hdpgpc/tests/test_online_warp.py stops there (tests/golden/make_golden.py `onlinew` reproduces it).  There is no
+            # reference behaviour to mirror; the batched warp fit itself (hgp_warp_batch_f64) serves include_batch(warp=True).
+            raise NotImplementedError("include_sample(with_warp=True): the reference's own path raises at its second beat "
+                                      "(GPI_HDP.py:3313); not built")
         if classify:
             raise NotImplementedError("include_sample(classify=True) has no caller in the reference and is not built")
         if self.n_outputs != 1:

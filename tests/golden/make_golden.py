@@ -728,7 +728,7 @@ def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5, leads=None, warp=Fa
 
 
 # ------------------------------------- SURVEY 8b Face 1 / configs[4]: the online step, GPI_HDP.include_sample
-def gen_include_sample(tag, rec, n, T_res=None, lead=0):
+def gen_include_sample(tag, rec, n, T_res=None, lead=0, with_warp=False):
     """Run the reference's online loop as hdpgpc/tests/test_online.py:41-83 drives it (n_f = 30, free_deg_MNIV = 20, warp
     off, theta injected) on the first n beats of a record - optionally resampled to T_res points by linear interpolation
     (BASELINE configs[4] names T = 256) - and record after every beat what the step decided and scored."""
@@ -744,15 +744,19 @@ def gen_include_sample(tag, rec, n, T_res=None, lead=0):
     sw = HDP.GPI_HDP(xb, x_basis_warp=xb[::2], n_outputs=1, kernels=None, model_type="dynamic", ini_lengthscale=3.0,
                      bound_lengthscale=(1.0, 20.0), ini_gamma=std_dif, ini_sigma=std, ini_outputscale=300.0, noise_warp=std * 0.1,
                      bound_sigma=bound_sigma, bound_gamma=bound_gamma, bound_noise_warp=(std * 0.01, std * 0.02),
-                     warp_updating=False, method_compute_warp="greedy", verbose=False, hmm_switch=True, max_models=100,
+                     warp_updating=bool(with_warp), method_compute_warp="greedy", verbose=False, hmm_switch=True, max_models=100,
                      mode_warp="rough", bayesian_params=True, inducing_points=False, estimation_limit=None, free_deg_MNIV=20)
     out = {"y": data[..., 0], "x_basis": xb[:, 0], "estimators": np.array([std, std_dif, *bound_sigma, *bound_gamma]),
-           "theta_inject": np.array(THETA_INJECT)}
+           "theta_inject": np.array(THETA_INJECT), "with_warp": np.array(bool(with_warp))}
     states, Ms, secs = [], [], []
     for i in range(n):
         t0 = time.time()
-        sw.include_sample(xb, data[i], with_warp=False)
+        sw.include_sample(xb, data[i], with_warp=bool(with_warp))   # hdpgpc/tests/test_online_warp.py:82 passes True
         secs.append(time.time() - t0)
+        if with_warp:   # what compute_warp_y returned for this beat: liks [M + 1], the warps and the warped beat per cluster
+            out[f"b{i}_liks"] = np.asarray(npy(sw.liks[-1]) if torch.is_tensor(sw.liks[-1]) else sw.liks[-1], dtype=np.float64)
+            out[f"b{i}_xw"] = np.stack([npy(v).reshape(-1) for v in sw.x_w[-1]])
+            out[f"b{i}_yw"] = np.stack([npy(v).reshape(-1) for v in sw.y_w[-1]])
         states.append(sw.actual_state)
         Ms.append(sw.M)
         out[f"b{i}_labels"] = npy(sw.resp_assigned[-1]).astype(np.int16)
@@ -860,6 +864,8 @@ if __name__ == "__main__":
         gen_cluster_learning("r102_2leads", "102", 300, 20)
     if "online90" in which:
         gen_include_sample("r102_n40", "102", 40)
+    if "onlinew" in which:
+        gen_include_sample("r102_n25_warp", "102", 25, with_warp=True)
     if "online256" in which and "trace" in which:
         gen_include_sample("r102_t256_n24", "102", 24, T_res=256)
     if "reload" in which:
