@@ -132,7 +132,11 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
 ) {
   using PB = PairsBand<NB>;
   constexpr int TP = 16 * NB, NH = NB / 2, NI = PB::nitems();
-  double ra[4][2][NH], re[4][2];
+#ifndef HGP_BAND_RING
+#define HGP_BAND_RING ((NB <= 6) ? 8 : 4)
+#endif
+  constexpr int RD = HGP_BAND_RING;   // ring slots (half-blocks in flight): NB <= 6 has the registers for eight
+  double ra[RD][2][NH], re[RD][2];
   d4 BJ[NH];
   // Every operand address of the sweeps is  (uniform base + compile-time constant) + ONE of two lane offsets: Mu is uniform
   // (the cluster index comes through v_readfirstlane), so the M' loads take the scalar-base form of global_load and the E reads
@@ -143,7 +147,7 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
     constexpr int t = decltype(tc)::value;
     constexpr auto it = PB::item(t);
     if constexpr (it.valid) {
-      constexpr int slot = t & 3, rm = PB::rows(it.J, it.h);
+      constexpr int slot = t % RD, rm = PB::rows(it.J, it.h);
       const unsigned moff = (unsigned)launder((int)moff0), eoff = (unsigned)launder((int)eoff0);   // opaque per fill: no merging / hoisting of the loads of different fills
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
@@ -162,14 +166,11 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
       }
     }
   };
-  fill(std::integral_constant<int, 0>{});
-  fill(std::integral_constant<int, 1>{});
-  fill(std::integral_constant<int, 2>{});
-  fill(std::integral_constant<int, 3>{});
+  static_for<0, RD>([&](auto tc) { fill(tc); });
   static_for<0, NI>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     constexpr auto it = PB::item(t);
-    constexpr int slot = t & 3, rm = PB::rows(it.J, it.h), J = it.J, h = it.h;
+    constexpr int slot = t % RD, rm = PB::rows(it.J, it.h), J = it.J, h = it.h;
     if constexpr (it.first) {
 #pragma unroll
       for (int i = 0; i < NH; ++i) BJ[i] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -181,7 +182,7 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
       for (int i = 0; i < NH; ++i)
         if ((rm >> i) & 1) BJ[i] = mfma(ra[slot][s_][i], re[slot][s_], BJ[i]);
     }
-    fill(std::integral_constant<int, t + 4>{});
+    fill(std::integral_constant<int, t + RD>{});
     if constexpr (it.last) {
       const int g = lane_in >> 4, c = lane_in & 15;
       const unsigned eoff = (unsigned)launder((int)eoff0);
@@ -245,7 +246,7 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
 // kernel the allocator spilled 126 VGPRs at NB = 8 (284 B of scratch per lane, 189 MB of scratch writes per launch, WRITE_SIZE);
 // apart they need none.  Without a list (a.fb == nullptr: NB < 6, HGP_PAIRS_GENERIC=1) the generic kernel takes every segment.
 template <int NB, bool BAND>
-__global__ __launch_bounds__(64 * WAVES) void k_pairs(PairsArgs a) {
+__global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsArgs a) {   // T <= 64: two workgroups per CU (the kernel sat 3 registers above that limit)
   constexpr int TP = 16 * NB;
   constexpr int NH = NB / 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
