@@ -255,7 +255,8 @@ struct EachArgs {
   int symmetric;             // caller guarantees Sigma == Sigma^T bit for bit: read the upper triangle only
 };
 
-template <int NB>
+// (SYM: one instantiation per loader - with both in one function the NB = 8 kernel spilled 290 VGPRs)
+template <int NB, bool SYM>
 __global__ __launch_bounds__(64 * WAVES, (NB <= 6) ? 2 : 1) void k_wave_score1(EachArgs a) {
   __shared__ __attribute__((aligned(16))) double scr_all[WAVES * DIAG_SCR];
   __shared__ __attribute__((aligned(16))) double dv_all[WAVES * 16 * NB];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 6) ? 2 : 1) void k_wave_score1(E
   for (int i = lane; i < 16 * NB; i += 64) dv[i] = (i < T) ? yr[i] - (mu ? mu[i] : 0.0) : 0.0;
   d4 U[NB * (NB + 1) / 2];
   d4 Rnone[NB];
-  if (a.symmetric) load_upper_only<NB>(U, S, T, T, lane);
+  if constexpr (SYM) load_upper_only<NB>(U, S, T, T, lane);
   else load_sym_upper<NB>(U, S, T, T, lane, scr);
   {
     double sh = a.seg_add ? a.seg_add[seg] : 0.0;
@@ -2132,10 +2133,10 @@ int hgp_score_each_f64(const double* Y, int ldy, const double* mean, long mean_s
   dim3 grid((n + WAVES - 1) / WAVES), blk(64 * WAVES);
   hipStream_t st = (hipStream_t)stream;
   switch (nb_for(T)) {
-    case 2: hipLaunchKernelGGL(k_wave_score1<2>, grid, blk, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_wave_score1<4>, grid, blk, 0, st, a); break;
-    case 6: hipLaunchKernelGGL(k_wave_score1<6>, grid, blk, 0, st, a); break;
-    default: hipLaunchKernelGGL(k_wave_score1<8>, grid, blk, 0, st, a); break;
+    case 2: if (a.symmetric) hipLaunchKernelGGL((k_wave_score1<2, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((k_wave_score1<2, false>), grid, blk, 0, st, a); break;
+    case 4: if (a.symmetric) hipLaunchKernelGGL((k_wave_score1<4, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((k_wave_score1<4, false>), grid, blk, 0, st, a); break;
+    case 6: if (a.symmetric) hipLaunchKernelGGL((k_wave_score1<6, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((k_wave_score1<6, false>), grid, blk, 0, st, a); break;
+    default: if (a.symmetric) hipLaunchKernelGGL((k_wave_score1<8, true>), grid, blk, 0, st, a); else hipLaunchKernelGGL((k_wave_score1<8, false>), grid, blk, 0, st, a); break;
   }
   return launch_status();
 }
