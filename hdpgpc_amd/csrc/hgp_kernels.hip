@@ -711,7 +711,10 @@ int launch_gemm(const GemmArgs& a0, int batch, hipStream_t st) {
     GemmArgs a = a0;
     a.boff = b0;
     const int nb = std::min(65535, batch - b0);
-    if (!a.tA && !a.tB && a.M % 32 == 0 && a.N % 32 == 0 && a.Kd % 32 == 0 && a.Kd > 128 && !env_on("HGP_GEMM_PLAIN")) {
+    // (only for launches that fill the chip: a single 256^3 product is 64 waves here against 256 in k_gemm - latency-bound,
+    // 25.8 vs ~12 us in the member step of the online path at T = 256)
+    if (!a.tA && !a.tB && a.M % 32 == 0 && a.N % 32 == 0 && a.Kd % 32 == 0 && a.Kd > 128 &&
+        (long)(a.M / 32) * (a.N / 32) * nb >= 2048 && !env_on("HGP_GEMM_PLAIN")) {
       const int nt2 = (a.M / 32) * (a.N / 32);
       hipLaunchKernelGGL(k_gemm22, dim3((nt2 + WAVES - 1) / WAVES, nb), dim3(64 * WAVES), 0, st, a);
       continue;
