@@ -312,3 +312,28 @@ def test_score_output_written_by_the_kernels():
         s1, _, _ = plan.loglik(x, y, want_logdet=False, sel=sel, score=True)
         assert torch.allclose(s1, -0.5 * q1 - 0.5 * T * math.log(2.0 * math.pi), rtol=1e-15, atol=0.0)
         assert torch.equal(q1, quad[torch.arange(N, device="cuda"), sel.long()])
+
+
+def test_more_segments_than_the_fall_back_list_holds():
+    """hgp_loglik_pairs_f64 launches the band / generic kernel pair in chunks of 65 536 segments (the capacity of the plan's
+    fall-back list): a batch beyond that - with non-banded segments on both sides of the chunk boundary, a per-pair
+    first_noise and a per-segment selection - must equal its pieces scored separately, bit for bit."""
+    N, K, T = 70000, 2, 90
+    b = orc.synthetic_batch(256, K, T, seed=5)
+    rng = np.random.default_rng(5)
+    x = np.tile(b["x"], (N // 256 + 1, 1))[:N].copy()
+    y = np.tile(b["y"], (N // 256 + 1, 1))[:N].copy()
+    for n in (3, 65535, 65536, 65537, 69999):
+        x[n] = x[n][::-1].copy()                   # reversed grid: not block-tridiagonal -> generic kernel through the list
+    plan = ops.PairsPlan(T, T, b["theta"]).update(dev(b["xb"]), dev(b["mean"]), dev(b["Sigma"]))
+    fn = dev(rng.uniform(0.0, 1.0, size=(N, K)))
+    X, Y = dev(x), dev(y)
+    q, l, i = plan.loglik(X, Y, first_noise=fn)
+    assert int(i.abs().max()) == 0
+    h = 40000
+    qa, la, _ = plan.loglik(X[:h].contiguous(), Y[:h].contiguous(), first_noise=fn[:h].contiguous())
+    qb, lb, _ = plan.loglik(X[h:].contiguous(), Y[h:].contiguous(), first_noise=fn[h:].contiguous())
+    assert torch.equal(torch.cat((qa, qb)), q) and torch.equal(torch.cat((la, lb)), l)
+    sel = torch.as_tensor(rng.integers(0, K, N), dtype=torch.int32, device="cuda")
+    qs, ls, _ = plan.loglik(X, Y, first_noise=fn.gather(1, sel.long().unsqueeze(1))[:, 0].contiguous(), sel=sel)
+    assert torch.equal(qs, q.gather(1, sel.long().unsqueeze(1))[:, 0]) and torch.equal(ls, l.gather(1, sel.long().unsqueeze(1))[:, 0])
