@@ -28,6 +28,7 @@ def _load():
         "hgp_gram_rbf_f64": (i32, [vp, i32, vp, i32, f64, f64, f64, vp, vp]),
         "hgp_potrf_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, vp]),
         "hgp_chol_inverse_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp]),
+        "hgp_chol_inverse_ws_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, vp]),
         "hgp_rts_chain_f64": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
         "hgp_lds_chain_scatter_f64": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
         "hgp_add_diag_mean_f64": (i32, [vp, vp, i32, i32, f64, vp, vp]),
@@ -60,6 +61,7 @@ def _load():
         "hgp_chol_inverse_rhs_batched_f64": (i32, [vp, i32, i32, f64, f64, vp, vp, vp, i32, vp, vp, vp]),
         "hgp_lds_chain_gather2_f64": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, vp, vp, vp, vp]),
         "hgp_lds_chain_finish2_f64": (i32, [i32] + [vp] * 22 + [i32, vp, vp]),
+        "hgp_copy_list_f64": (i32, [vp, i32, i64, vp]),
         "hgp_lds_chain_gather2_batched_f64": (i32, [vp, i32, i32, vp]),
         "hgp_lds_chain_finish2_batched_f64": (i32, [vp, i32, i32, vp]),
         "hgp_trsv_lower_solve_f64": (i32, [vp, i32, vp, i32, vp, vp, vp]),

@@ -188,7 +188,7 @@ __device__ __forceinline__ void chain_gather2_body(const Gather2Args& a, double 
         const int k = 6 + (int)(j / a.T);
         a.out[i] = a.st[k][p * a.T + (j % a.T)];
       }
-      if (a.Y && i < a.T) a.y_out[i] = a.Y[(p - a.y_row0) * a.T + i];
+      if (a.Y && i < a.T) a.y_out[i] = a.Y[(a.y_row0 < 0 ? 0 : p - a.y_row0) * a.T + i];   // y_row0 < 0: Y is the observation itself
     } else {
       const long e = i - total;                 // element of R' [2,T,T]
       const int mtx = (int)(e / tt);
@@ -229,7 +229,11 @@ __device__ __forceinline__ void chain_finish2_body(const Finish2Args& a, int& la
   const long p = a.pos[0], nxt = p + 1;
   const double n0n = bad ? n0 : n0 + 1.0;
   const double scl = n0n / (n0n - 2.0);
-  const double ann = a.annealing ? 1.0 / (Nf * Nf) : 0.0;
+  const double ann = (a.annealing & 1) ? 1.0 / (Nf * Nf) : 0.0;
+  // online path (hdpgpc_amd/online_chain.py): bit 1 = dry run - a CANDIDATE step: the new rows are written behind the chain's
+  // end (row pos + 1) but the distributions W, the counters and the position stay as they are; bit 2 = the previous smoothed
+  // state is not rewritten (a step without backwards_pair: the committed online step, GPI_HDP.py:2186-2196)
+  const bool dry = (a.annealing & 2) != 0, keep_prev = (a.annealing & 4) != 0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 2 * tt; i += (long)gridDim.x * 256) {
     const bool obs = i >= tt;           // item 0 = internal (A, Gamma): (f_post, f_sm_prev); item 1 = observation (C, Sigma): (y, f_post)
     const long e = obs ? i - tt : i;
@@ -241,9 +245,11 @@ __device__ __forceinline__ void chain_finish2_body(const Finish2Args& a, int& la
       m = ((n0 - 2.0) * m + a.part[i]) / (n0 - 1.0);
       r = a.Snew[i];
       sc = ((n0 - 2.0) * sc + er * ec) / (n0 - 1.0);
-      a.W[i] = m;
-      a.W[2 * tt + i] = r;
-      a.W[4 * tt + i] = sc;
+      if (!dry) {
+        a.W[i] = m;
+        a.W[2 * tt + i] = r;
+        a.W[4 * tt + i] = sc;
+      }
     }
     (obs ? a.stC : a.stA)[nxt * tt + e] = m;
     double* sg = obs ? a.stS : a.stG;
@@ -252,12 +258,12 @@ __device__ __forceinline__ void chain_finish2_body(const Finish2Args& a, int& la
       const double cp = a.c_post[e];
       a.stP[nxt * tt + e] = cp;
       a.stPsm[nxt * tt + e] = cp;
-      a.stPsm[p * tt + e] = a.P_sm_prev[e];
+      if (!keep_prev) a.stPsm[p * tt + e] = a.P_sm_prev[e];
       if (e < T) {
         const double f = a.f_post[e];
         a.stF[nxt * T + e] = f;
         a.stFsm[nxt * T + e] = f;
-        a.stFsm[p * T + e] = a.f_sm_prev[e];
+        if (!keep_prev) a.stFsm[p * T + e] = a.f_sm_prev[e];
       }
     }
   }
@@ -268,11 +274,13 @@ __device__ __forceinline__ void chain_finish2_body(const Finish2Args& a, int& la
   }
   __syncthreads();
   if (last && threadIdx.x == 0) {
-    a.n0[0] = n0n;
-    a.Nf[0] = Nf;
+    if (!dry) {
+      a.n0[0] = n0n;
+      a.Nf[0] = Nf;
+      a.pos[0] = nxt;
+    }
     a.bad_count[0] += bad ? 1 : 0;
     if (a.bad_count[1] == 0 && (a.info1[0] | a.info1[1]) != 0) a.bad_count[1] = (int32_t)nxt;
-    a.pos[0] = nxt;
     a.sync[0] = 0;
   }
 }
@@ -289,9 +297,34 @@ __global__ __launch_bounds__(256) void k_chain_finish2_b(const Finish2Args* __re
 }
 #pragma clang fp contract(on)
 
+// -------------------------------------------------------------------------------------------- list of copies
+// The online step assembles the inputs of ONE batched a8 / a9 launch from rows of many clusters' stacks (three members per
+// candidate, two parameter pairs): dozens of T- and T^2-sized copies as one launch instead of one hipMemcpyAsync each.
+__global__ __launch_bounds__(256) void k_copy_list(const hgp_copy_item* __restrict__ items) {
+  const hgp_copy_item q = items[blockIdx.y];
+  const long n2 = q.n >> 1;                                   // pairs of doubles (src / dst 16-byte aligned when n is even)
+  const bool vec = ((reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst)) & 15) == 0;
+  if (vec) {
+    const double2* s2 = reinterpret_cast<const double2*>(q.src);
+    double2* d2 = reinterpret_cast<double2*>(q.dst);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) d2[i] = s2[i];
+    if ((q.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) q.dst[q.n - 1] = q.src[q.n - 1];
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < q.n; i += (long)gridDim.x * 256) q.dst[i] = q.src[i];
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int hgp_copy_list_f64(const hgp_copy_item* items_dev, int n_items, long max_n, void* stream) {
+  if (n_items == 0) return 0;
+  if (!items_dev || n_items < 0 || n_items > 65535 || max_n <= 0) return -1;
+  const long blocks = std::min<long>(64, (max_n / 2 + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_copy_list, dim3((unsigned)blocks, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+  return launch_status();
+}
 
 int hgp_gemm_list_f64(const hgp_gemm_item* items_dev, int n_items, int total_tiles, void* stream) {
   if (n_items == 0) return 0;

@@ -1,0 +1,378 @@
+"""The online step's member updates as PERSISTENT chains (BASELINE configs[4]; GPI_HDP.py:1906-2208 with
+GPI_model.py:325-375,705-716,966-1115,1300-1344).
+
+Per beat the reference asks every cluster "what would you look like with this beat?": a deep copy, one Kalman update
+(estimate_new), the same update again (include_weighted_sample), the two-step smoother (backwards_pair), the two MNIW updates
+(bayesian_new_params), then the latent-transition scores of ALL the copy's members and the MNIW likelihood of its new
+parameters - candidate after candidate, ~150 dependent launches each (round 3: 3 700 launches and 62-80 ms per beat at T = 256).
+Nothing a candidate computes feeds another one.  Here every cluster model of a lead owns a slot of an ``OnlinePool``:
+
+* its per-step lists live in growing stacks ([rows, T, T]; the model's lists are views, a12) with the device-side position,
+  counters and MNIW distributions of GPI_model._chain_alloc - the cluster IS a chain that is never torn down;
+* ``candidates(y)`` runs the member step of ALL clusters side by side with the level-fused lists of the offline chains
+  (hgp_gemm_list_f64, one launch per dependency level over every cluster's items; the two inversions batched over
+  [4 x clusters] / [2 x clusters] matrices) as a DRY run: the new rows land behind each chain's end, the re-smoothed previous
+  state stays in the step's buffers, nothing of the cluster changes (finish flags 2 | 4, include/hdpgpc_hip.h).  One Kalman
+  update serves estimate_new and the inclusion (the last filtered and smoothed states of an online chain coincide);
+* of a candidate's latent-transition scores only three can differ from the cluster's cached ones (member 0 reads the LAST
+  transition parameters, the previous member was re-smoothed, the new member): 3 x clusters a8 items and 2 x clusters a9 items
+  are gathered by ONE copy-list launch and scored by one batched call each;
+* ``commit(g, ...)`` is the same step for the cluster that absorbs the beat, for real and without the smoother (the reference's
+  commit does not call backwards_pair, GPI_HDP.py:2186-2196): the previous smoothed mean takes the smoother's place in the
+  MNIW update and the previous row is left alone (finish flag 4).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _ffi, ops
+from .GPI_model import LOG2PI, StackList, matrix_normal_inv_wishart
+
+f64 = torch.float64
+_STACKS = ("A", "G", "C", "S", "Psm", "P", "F", "Fsm")          # order of hgp_chain_gather_desc.st
+_LISTS = {"A": "A", "G": "Gamma", "C": "C", "S": "Sigma", "Psm": "cov_f_sm", "P": "cov_f", "F": "f_star", "Fsm": "f_star_sm"}
+_SH4 = ("X4", "RH4", "Z4", "Y4", "WK4")
+_SH2 = ("S__", "S_", "Zs", "Y3", "WK2")
+
+
+class _Slot:
+    __slots__ = ("g", "ch", "rows", "N", "ini_noise", "def_diag", "bad0")
+
+
+class OnlinePool:
+    """All cluster models of one lead of an online GPI_HDP, as persistent chains (see the module docstring)."""
+
+    def __init__(self, T, device, annealing, cap=8):
+        self.T, self.device, self.annealing = int(T), device, bool(annealing)
+        self.slots = []
+        self.cap = 0
+        self.merged = None
+        self._alloc(cap)
+        self.ybuf = torch.zeros((1, T), dtype=f64, device=device)
+
+    # ------------------------------------------------------------------ storage
+    def _alloc(self, cap):
+        T, dev = self.T, self.device
+        new = lambda *shape: torch.zeros(shape, dtype=f64, device=dev)            # noqa: E731
+        self.cap = cap
+        self.WS = 6 * T * T + 2 * T
+        self.ws_all = new(cap, self.WS)
+        self.shared = {k: new(cap * 4, T, T) for k in _SH4}
+        self.shared.update({k: new(cap * 2, T, T) for k in _SH2})
+        self.shared["i4"] = torch.zeros(cap * 4, dtype=torch.int32, device=dev)
+        self.shared["i2"] = torch.zeros(cap * 2, dtype=torch.int32, device=dev)
+        self.rhs_on = torch.tensor([1, 1, 0, 0] * cap, dtype=torch.int32, device=dev)
+        self.bad_all = torch.zeros((cap, 2), dtype=torch.int32, device=dev)      # committed steps
+        self.badc_all = torch.zeros((cap, 2), dtype=torch.int32, device=dev)     # candidate steps (cleared per beat)
+        self.sync_all = torch.zeros(cap, dtype=torch.int32, device=dev)
+        self.est_mean = new(cap, T)
+        # inputs of the batched a8 (three members per cluster) and a9 (two parameter pairs per cluster) calls
+        self.LF_cur, self.LF_prev = new(cap * 3, T), new(cap * 3, T)
+        self.LA, self.LG, self.LC = new(cap * 3, T, T), new(cap * 3, T, T), new(cap * 3, T, T)
+        self.MN_M, self.MN_S, self.MN_mean, self.MN_scale = (new(cap * 2, T, T) for _ in range(4))
+
+    def _grow(self):
+        """Twice the cluster capacity: the per-cluster slices of the shared buffers move, so every slot's lists are rebuilt."""
+        old = self.slots
+        self.slots = []
+        self._alloc(self.cap * 2)
+        for sl in old:
+            self._bind(sl)
+        self.merged = None
+
+    def _views(self, c):
+        v = {k: self.shared[k][4 * c:4 * c + 4] for k in ("X4", "RH4", "Z4", "Y4", "i4")}
+        v.update({k: self.shared[k][2 * c:2 * c + 2] for k in ("S__", "S_", "Zs", "Y3", "i2")})
+        return v
+
+    def _bind(self, sl):
+        """Give the slot its index, its slices of the shared buffers and its level lists."""
+        c = len(self.slots)
+        sl.g._slot = c
+        ch = sl.ch
+        ch["ws"] = self.ws_all[c]
+        ch["bad"], ch["sync"] = self.bad_all[c], self.sync_all[c:c + 1]
+        ch["Y"], ch["y_row0"] = self.ybuf, -1
+        sl.g._chain_lists(ch, views=self._views(c))
+        T, tt = self.T, self.T * self.T
+        Cw = ch["ws"][2 * tt:3 * tt].view(T, T)
+        ch["lv"][6].add(Cw, ch["bufs"]["f_post"], self.est_mean[c])          # C_last f_post: the mean estimate_new scores against
+        dd = sl.g
+        self.MN_mean[2 * c].copy_(dd.C_def), self.MN_mean[2 * c + 1].copy_(dd.A_def)
+        self.MN_scale[2 * c].copy_(dd.Sigma_def), self.MN_scale[2 * c + 1].copy_(dd.Gamma_def)
+        self.slots.append(sl)
+
+    @staticmethod
+    def supports(g):
+        """The chain step covers: dynamic model, no estimation limit, at least one member, last filtered = last smoothed state
+        (always true for a chain grown online), no tracked rank-1 factor."""
+        if g.N < 1 or g.estimation_limit != np.inf or g._rank1_on() or not bool(torch.any(g.Gamma[-1] != 0)):
+            return False
+        n = len(g.f_star)
+        if not (n == len(g.f_star_sm) == len(g.cov_f) == len(g.cov_f_sm) == len(g.A) == len(g.Gamma) == len(g.C) == len(g.Sigma)):
+            return False
+        return bool(torch.equal(g.f_star[-1], g.f_star_sm[-1])) and bool(torch.equal(g.cov_f[-1], g.cov_f_sm[-1]))
+
+    def adopt(self, g):
+        """Move the model's per-step lists into a slot's stacks (the model keeps reading them through views)."""
+        if len(self.slots) == self.cap:
+            self._grow()
+        T, dev = self.T, self.device
+        L = len(g.f_star)
+        sl = _Slot()
+        sl.g, sl.N, sl.rows = g, L - 1, max(8, 2 * L)
+        ch = {}
+        for key in _STACKS:
+            lst = getattr(g, _LISTS[key])
+            shape = (T, 1) if key in ("F", "Fsm") else (T, T)
+            buf = torch.zeros((sl.rows,) + shape, dtype=f64, device=dev)
+            buf[:L] = (lst.stack() if isinstance(lst, StackList) else torch.stack(list(lst))).reshape((L,) + shape)
+            ch[key] = buf
+        ch["pos"] = torch.tensor([L - 1], dtype=torch.int64, device=dev)
+        ch["Nf"] = torch.tensor([float(g.N)], dtype=f64, device=dev)
+        ch["n0"] = torch.tensor([float(g.internal_params.n0)], dtype=f64, device=dev)
+        eye = torch.eye(T, dtype=f64, device=dev)
+        mi, mo = g.internal_params, g.observation_params
+        ch["W"] = torch.stack((torch.stack((mi.m_mean, mo.m_mean)),
+                               torch.stack((eye if mi.m_r_cov is None else mi.m_r_cov, eye if mo.m_r_cov is None else mo.m_r_cov)),
+                               torch.stack((mi.scale, mo.scale)))).contiguous()
+        sl.ch = ch
+        sl.ini_noise = 1e-2 * float(torch.mean(torch.diagonal(g.Sigma[0])))                       # log_sq_error's `first` inflation
+        sl.def_diag = all(bool(torch.equal(s_, torch.diag(torch.diagonal(s_)))) for s_ in (g.Sigma_def, g.Gamma_def))
+        sl.bad0 = 0
+        self._bind(sl)
+        self._rebind_lists(sl, float(mi.n0))
+        self.merged = None
+        return sl
+
+    def _rebind_lists(self, sl, n0):
+        """The model's lists and MNIW objects as views of the slot's stacks."""
+        g, ch, L = sl.g, sl.ch, sl.N + 1
+        for key in _STACKS:
+            setattr(g, _LISTS[key], StackList(ch[key][:L]))
+        W = ch["W"]
+        g.internal_params = matrix_normal_inv_wishart(W[0, 0], W[1, 0], n0, W[2, 0])
+        g.observation_params = matrix_normal_inv_wishart(W[0, 1], W[1, 1], n0, W[2, 1])
+        g._stk = {k: v for k, v in g._stk.items() if k in ("_lat_all",)}
+
+    def _more_rows(self, sl):
+        ch = sl.ch
+        rows = sl.rows * 2
+        for key in _STACKS:
+            buf = torch.zeros((rows,) + tuple(ch[key].shape[1:]), dtype=f64, device=self.device)
+            buf[:sl.rows] = ch[key]
+            ch[key] = buf
+        sl.rows = rows
+        lat = sl.g._stk.get("_lat_all")
+        self._rebind_lists(sl, float(sl.g.internal_params.n0))
+        if lat is not None:           # the key holds data pointers of the old stacks
+            sl.g._stk["_lat_all"] = (self._lat_key(sl.g), lat[1])
+        self.merged = None
+
+    # ------------------------------------------------------------------ launch tables
+    def _prepare(self):
+        """Descriptor arrays and merged level lists for the current set of slots (rebuilt when a slot is added or moves)."""
+        p = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+        T = self.T
+        gd, fd_dry, fd_real = [], [], []
+        for c, sl in enumerate(self.slots):
+            ch, b = sl.ch, sl.ch["bufs"]
+            g = _ffi.ChainGatherDesc()
+            for i, k in enumerate(_STACKS):
+                g.st[i] = ch[k].data_ptr()
+            g.pos, g.out, g.Y, g.y_out, g.W, g.Rp = p(ch["pos"]), p(ch["ws"]), p(self.ybuf), p(b["y"]), p(ch["W"]), p(b["X4"][2:4])
+            g.y_row0, g.T = -1, T
+            gd.append(g)
+            for flags, bad, lst in ((2 | 4, self.badc_all[c], fd_dry), (4, self.bad_all[c], fd_real)):
+                f = _ffi.ChainFinishDesc()
+                f.f_post, f.c_post, f.f_sm_prev, f.P_sm_prev, f.y = p(b["f_post"]), p(b["c_post"]), p(b["f_sm_prev"]), p(b["P_sm_prev"]), p(b["y"])
+                f.part, f.Snew, f.info1, f.info2 = p(b["part"]), p(b["S__"]), p(ch["i4"]), p(ch["i2"])
+                f.W, f.n0, f.Nf, f.bad_count = p(ch["W"]), p(ch["n0"]), p(ch["Nf"]), p(bad)
+                f.stA, f.stG, f.stC, f.stS = p(ch["A"]), p(ch["G"]), p(ch["C"]), p(ch["S"])
+                f.stF, f.stFsm, f.stP, f.stPsm = p(ch["F"]), p(ch["Fsm"]), p(ch["P"]), p(ch["Psm"])
+                f.pos, f.sync, f.T, f.annealing = p(ch["pos"]), p(ch["sync"]), T, int(self.annealing) | flags
+                lst.append(f)
+        from .chain_batch import _descs
+        self.gdev, self.fdev_dry, self.fdev_real = _descs(gd, self.device), _descs(fd_dry, self.device), _descs(fd_real, self.device)
+        n_lv = len(self.slots[0].ch["lv"])
+        self.per = [len(self.slots[0].ch["lv"][l]._items) for l in range(n_lv)]
+        self.merged = [ops.GemmList.concat([sl.ch["lv"][l] for sl in self.slots]).finalize() for l in range(n_lv)]
+        self.riding = self.slots[0].ch["riding"]
+        # static part of the copy table (base pointers of the stacks and step buffers of every slot)
+        self._base = np.array([[sl.ch[k].data_ptr() for k in _STACKS] for sl in self.slots], dtype=np.int64)
+        self._bufp = np.array([[sl.ch["bufs"][k].data_ptr() for k in ("f_post", "f_sm_prev", "P_sm_prev")] for sl in self.slots],
+                              dtype=np.int64)
+
+    def _step(self, lo, hi, dry):
+        """The member step of slots [lo, hi): one launch per dependency level (GPI_model._chain_step2 for many chains)."""
+        if self.merged is None:
+            self._prepare()
+        T, k, sh, per, mg = self.T, hi - lo, self.shared, self.per, self.merged
+        gsz, fsz = ctypes.sizeof(_ffi.ChainGatherDesc), ctypes.sizeof(_ffi.ChainFinishDesc)
+        st = ops._stream
+        _ffi.check(_ffi.lib.hgp_lds_chain_gather2_batched_f64(ctypes.c_void_p(self.gdev.data_ptr() + lo * gsz), k, T, st()), "chain_gather2_batched")
+        run = lambda l: mg[l].run_range(per[l] * lo, per[l] * k)        # noqa: E731
+        s4, s2 = slice(4 * lo, 4 * hi), slice(2 * lo, 2 * hi)
+        for l in range(4):
+            run(l)
+        if self.riding:
+            ops.chol_inverse_rhs(sh["X4"][s4], sh["Z4"][s4], sh["RH4"][s4], sh["Y4"][s4], sh["i4"][s4], rhs_on=self.rhs_on[s4])
+        else:
+            ops.chol_inverse(sh["X4"][s4], out=sh["Z4"][s4], info=sh["i4"][s4], work=sh["WK4"][s4])
+            run(10)
+        for l in range(4, 8):
+            run(l)
+        if not dry:        # no smoother in the committed step: the previous smoothed mean stands where f_sm_prev would
+            for sl in self.slots[lo:hi]:
+                tt = T * T
+                sl.ch["bufs"]["f_sm_prev"].copy_(sl.ch["ws"][6 * tt + T:6 * tt + 2 * T])
+        run(8)
+        if self.riding:
+            ops.chol_inverse_rhs(sh["S__"][s2], sh["Zs"][s2], sh["S_"][s2], sh["Y3"][s2], sh["i2"][s2], rhs_trans=True, add_diag=1e-8)
+        else:
+            ops.chol_inverse(sh["S__"][s2], 0.0, 1e-8, out=sh["Zs"][s2], info=sh["i2"][s2], work=sh["WK2"][s2])
+            run(11)
+        run(9)
+        fdev = self.fdev_dry if dry else self.fdev_real
+        _ffi.check(_ffi.lib.hgp_lds_chain_finish2_batched_f64(ctypes.c_void_p(fdev.data_ptr() + lo * fsz), k, T, st()), "chain_finish2_batched")
+
+    # ------------------------------------------------------------------ candidates
+    def candidates(self, y, t_new, q_lat_cols, indexes):
+        """Every cluster with the beat y [T] added (dry run).  q_lat_cols [T_all, M']: the clusters' current latent-transition
+        columns in SLOT order; indexes[c] = member segment ids of slot c.  Returns
+        (est [M] device: estimate_new's score, cols [T_all, M] device: the candidates' latent-transition columns,
+         lds [M] host floats: return_LDS_param_likelihood of the candidates)."""
+        M, T = len(self.slots), self.T
+        tt = T * T
+        for sl in self.slots:
+            if sl.N + 2 > sl.rows:
+                self._more_rows(sl)
+        if self.merged is None:
+            self._prepare()
+        self.ybuf.copy_(y.reshape(1, T))
+        self.badc_all[:M].zero_()
+        self._step(0, M, dry=True)
+        # estimate_new: the beat against (C_last f_post, Sigma_last), `first` inflation for one-member clusters
+        Y = self.ybuf.expand(M, T).contiguous()
+        add = np.array([sl.ini_noise if sl.N == 1 else 0.0 for sl in self.slots])
+        ar = np.arange(M, dtype=np.int32)
+        quad, _, info = ops.score_each(Y, self.est_mean, self.ws_all[0, 3 * tt:], ar, ar, add, strides=(T, self.WS))
+        est = -0.5 * quad - 0.5 * T * LOG2PI
+        # a8 / a9 inputs by ONE copy-list launch.  Rows: N = members so far = index of the last row; N + 1 = the dry run's row
+        N = np.array([sl.N for sl in self.slots], dtype=np.int64)
+        one = N == 1
+        base, bufp = self._base, self._bufp
+        iA, iG, iC, iS, iPsm, iP, iF, iFsm = range(8)
+        row = lambda k, r, n: base[:, k] + r * (8 * n)                           # noqa: E731  (byte address of a stack row)
+        f_post, f_smp, P_smp = bufp[:, 0], bufp[:, 1], bufp[:, 2]
+        src, dst, cnt = [], [], []
+
+        def put(s, dbuf, j, n):
+            src.append(s), dst.append(dbuf.data_ptr() + (np.arange(M, dtype=np.int64) * (dbuf.shape[0] // self.cap) + j) * (8 * n))
+            cnt.append(np.full(M, n, dtype=np.int64))
+
+        # member 0: cur = prev = row 1, cov = row 1 (the re-smoothed one when it is also the previous member), par = the NEW row
+        f1 = np.where(one, f_smp, row(iFsm, 1, T))
+        put(f1, self.LF_cur, 0, T), put(f1, self.LF_prev, 0, T)
+        put(row(iA, N + 1, tt), self.LA, 0, tt), put(row(iG, N + 1, tt), self.LG, 0, tt)
+        put(np.where(one, P_smp, row(iPsm, 1, tt)), self.LC, 0, tt)
+        # member N - 1 (N >= 2; a repeat of member 0's inputs otherwise, ignored): cur = re-smoothed row N, prev / cov = row N - 1, par = N
+        Nm = np.maximum(N - 1, 1)
+        put(f_smp, self.LF_cur, 1, T), put(row(iFsm, Nm, T), self.LF_prev, 1, T)
+        put(row(iA, N, tt), self.LA, 1, tt), put(row(iG, N, tt), self.LG, 1, tt), put(row(iPsm, Nm, tt), self.LC, 1, tt)
+        # the new member: cur = f_post, prev / cov = the re-smoothed row N, par = the NEW row
+        put(f_post, self.LF_cur, 2, T), put(f_smp, self.LF_prev, 2, T)
+        put(row(iA, N + 1, tt), self.LA, 2, tt), put(row(iG, N + 1, tt), self.LG, 2, tt), put(P_smp, self.LC, 2, tt)
+        # a9: (C, Sigma) and (A, Gamma) of the NEW row against their priors
+        put(row(iC, N + 1, tt), self.MN_M, 0, tt), put(row(iS, N + 1, tt), self.MN_S, 0, tt)
+        put(row(iA, N + 1, tt), self.MN_M, 1, tt), put(row(iG, N + 1, tt), self.MN_S, 1, tt)
+        table = np.stack([np.concatenate(src), np.concatenate(dst), np.concatenate(cnt)], axis=1)
+        tdev = torch.from_numpy(table).to(self.device)
+        ops.copy_list(tdev, table.shape[0], tt)
+        lat, info_l = ops.lat_error(self.LF_cur[:3 * M], self.LF_prev[:3 * M], self.LA[:3 * M], self.LG[:3 * M], self.LC[:3 * M])
+        lat = lat - 0.5 * T * LOG2PI
+        mn, info_m = ops.mniw_loglik(self.MN_M[:2 * M], self.MN_S[:2 * M], self.MN_mean[:2 * M], None, self.MN_scale[:2 * M],
+                                     scale_is_diagonal=all(sl.def_diag for sl in self.slots))
+        lds_dev = torch.sum(mn.view(M, 2), dim=1) / T * 100.0
+        # one host round trip for everything the loop branches on
+        flat = torch.cat([lds_dev, info.to(f64), info_l.to(f64), info_m.to(f64), self.badc_all[:M].reshape(-1).to(f64)]).cpu().numpy()
+        lds = flat[:M]
+        if flat[M:7 * M].any():                   # score [M] / a8 [3 M] / a9 [2 M] infos
+            bad = int(np.nonzero(flat[M:7 * M])[0][0])
+            what = "log_sq_error" if bad < M else ("log_lat_error" if bad < 4 * M else "log_likelihood_MNIW")
+            raise torch.linalg.LinAlgError(f"{what}: the input is not positive-definite (online candidate step)")
+        badc = flat[7 * M:].reshape(M, 2)
+        if badc[:, 1].any():
+            raise torch.linalg.LinAlgError("posterior / backwards_pair: the input is not positive-definite (online candidate step)")
+        # the candidates' columns: the cluster's own column with (up to) three entries replaced
+        cols = q_lat_cols.clone()
+        rr, cc, vv = [], [], []
+        for c, sl in enumerate(self.slots):
+            idx = indexes[c]
+            rr += [idx[0], t_new]
+            cc += [c, c]
+            vv += [3 * c, 3 * c + 2]
+            if sl.N >= 2:
+                rr.append(idx[sl.N - 1]), cc.append(c), vv.append(3 * c + 1)
+        dev = self.device
+        cols[torch.as_tensor(rr, device=dev), torch.as_tensor(cc, device=dev)] = lat[torch.as_tensor(vv, device=dev)]
+        return est, cols, lds
+
+    # ------------------------------------------------------------------ commit
+    @staticmethod
+    def _lat_key(g, h_ini=1.0):
+        return (h_ini, len(g.indexes), len(g.Gamma), g.f_star_sm[-1].data_ptr(), g.cov_f_sm[-1].data_ptr())
+
+    def commit(self, g, index, x_train, y):
+        """include_weighted_sample(h = 1) + bayesian_new_params(1) of the cluster that absorbs the beat (no smoother)."""
+        sl = self.slots[g._slot]
+        T = self.T
+        if sl.N + 2 > sl.rows:
+            self._more_rows(sl)
+        if self.merged is None:
+            self._prepare()
+        lat_old = g._stk.get("_lat_all")
+        if lat_old is not None and lat_old[0] != self._lat_key(g):
+            lat_old = None
+        yv = g.cond_to_torch(y).reshape(-1, 1)
+        self.ybuf.copy_(yv.reshape(1, T))
+        c = g._slot
+        self._step(c, c + 1, dry=False)
+        bad = self.bad_all[c].tolist()                       # the reference looks at its LinAlgError here too (GPI_model.py:1068)
+        if bad[1] != 0:
+            raise torch.linalg.LinAlgError("posterior: the input is not positive-definite (online step)")
+        updated = bad[0] == sl.bad0
+        sl.bad0 = bad[0]
+        if not updated and g.verbose:
+            print("Alg error matrix ill conditioned.")
+        sl.N += 1
+        g.N += 1
+        g.indexes.append(int(index))
+        g.x_train.append(x_train)
+        g.y_train.append(yv)
+        self._rebind_lists(sl, float(g.internal_params.n0) + (1.0 if updated else 0.0))
+        # latent-transition scores: member 0 now reads the new last parameters, the new member is added; the rest is unchanged
+        if lat_old is not None:
+            n = sl.N                                          # members now; rows 0..n
+            ch = sl.ch
+            fs, ps = ch["Fsm"], ch["Psm"]
+            cur = torch.stack((fs[1], fs[n])).reshape(2, T)
+            prv = torch.stack((fs[1], fs[n - 1])).reshape(2, T)
+            A2, G2 = torch.stack((ch["A"][n], ch["A"][n])), torch.stack((ch["G"][n], ch["G"][n]))
+            C2 = torch.stack((ps[1], ps[n - 1]))
+            out, info = ops.lat_error(cur, prv, A2, G2, C2)
+            ops.raise_on_info(info, "log_lat_error")
+            out = out - 0.5 * T * LOG2PI
+            new = torch.cat([out[0:1], lat_old[1][1:], out[1:2]])
+            g._stk["_lat_all"] = (self._lat_key(g), new)
+
+
+class CandidateView:
+    """What the one-sample bound asks of a candidate cluster (offline_loop.full_LDS_elbo): its MNIW parameter likelihood."""
+
+    def __init__(self, value):
+        self._v = float(value)
+
+    def lds_param_likelihood_value(self):
+        return self._v

@@ -21,7 +21,9 @@ def env_flag(name):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream (torch.cuda.current_stream() builds a Stream object: 9 us per call, and the
+    # online step makes hundreds of calls per beat)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _dev64(t, name):
@@ -70,18 +72,30 @@ def potrf_batched(A, jitter_rel=1e-8, add_diag=0.0, want_inv=False, want_logdet=
     return tuple(out)
 
 
-def chol_inverse(A, jitter_rel=0.0, add_diag=0.0, out=None, info=None):
+def chol_inverse(A, jitter_rel=0.0, add_diag=0.0, out=None, info=None, work=None):
     """Z = chol(0.5 (A + A^T) + shift I)^{-1} for a batch [b,T,T] (T <= 256; A untouched).  Returns (Z, info); `out` / `info`
-    may be caller-allocated (capture-safe, no allocation)."""
+    may be caller-allocated (capture-safe, no allocation).  work [b,T,T] (optional, T > 128): large batches factor once into
+    it and take L^-1 from L (hgp_chol_inverse_ws_f64) instead of one factorisation per block column."""
     A = _dev64(A, "A")
     A3 = A if A.dim() == 3 else A.unsqueeze(0)
     b, T, _ = A3.shape
     Z = torch.empty_like(A3) if out is None else out
     if info is None:
         info = torch.zeros(b, dtype=torch.int32, device=A.device)
+    if work is not None:
+        if work.numel() < A3.numel():
+            raise ValueError("chol_inverse: workspace smaller than the batch")
+        _ffi.check(_ffi.lib.hgp_chol_inverse_ws_f64(_ptr(A3), T, b, float(jitter_rel), float(add_diag), _ptr(Z), _ptr(_dev64(work, "work")),
+                                                    _ptr(info), _stream()), "chol_inverse_ws")
+        return Z, info
     _ffi.check(_ffi.lib.hgp_chol_inverse_batched_f64(_ptr(A3), T, b, float(jitter_rel), float(add_diag), _ptr(Z), _ptr(info),
                                                      _stream()), "chol_inverse")
     return Z, info
+
+
+def copy_list(items_dev, n_items, max_n):
+    """n_items copies dst[0..n) = src[0..n) described by the device-resident int64 table items_dev [n_items, 3] = (src, dst, n)."""
+    _ffi.check(_ffi.lib.hgp_copy_list_f64(_ptr(items_dev), int(n_items), int(max_n), _stream()), "copy_list")
 
 
 MAX_CHUNK = 64  # segments per work item: one factorisation is reused for up to this many right-hand sides
@@ -106,19 +120,21 @@ def build_items(mat_of_group, add_of_group, group_sizes):
 
 
 def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids=None, jitter_rel=1e-8,
-                 want_logdet=False, want_info=True, item_mean=None):
+                 want_logdet=False, want_info=True, item_mean=None, strides=None):
     """a4+a6: quad[n] = (Y[n]-mean[s])^T cov_s^{-1} (Y[n]-mean[s]) for the segments of each work item.
 
     Y [N,T]; mean [S,T] or None; Sigma [S,T,T]; item_* host or device int/float arrays; seg_ids [sum cnt] or None.
     """
     Y = _dev64(Y, "Y")
-    Sigma = _dev64(Sigma, "Sigma")
     dev = Y.device
     N, T = Y.shape
-    if Sigma.dim() == 2:
-        Sigma = Sigma.unsqueeze(0)
-    if mean is not None:
-        mean = _dev64(mean.reshape(-1, T), "mean")
+    if strides is None:       # strides = (mean_stride, sigma_stride) in doubles: states that sit inside larger per-cluster records
+        Sigma = _dev64(Sigma, "Sigma")
+        if Sigma.dim() == 2:
+            Sigma = Sigma.unsqueeze(0)
+        if mean is not None:
+            mean = _dev64(mean.reshape(-1, T), "mean")
+    mstride, sstride = (T, T * T) if strides is None else (int(strides[0]), int(strides[1]))
 
     def up(a, dt):
         return a.to(device=dev, dtype=dt).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
@@ -130,22 +146,24 @@ def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids
     quad = torch.zeros(N, dtype=torch.float64, device=dev)
     logdet = torch.zeros(N, dtype=torch.float64, device=dev) if want_logdet else None
     info = torch.zeros(N, dtype=torch.int32, device=dev) if want_info else None
-    _ffi.check(_ffi.lib.hgp_score_groups_f64(_ptr(Y), T, _ptr(mean), T, _ptr(Sigma), T * T, T, _ptr(im), _ptr(imean),
+    _ffi.check(_ffi.lib.hgp_score_groups_f64(_ptr(Y), T, _ptr(mean), mstride, _ptr(Sigma), sstride, T, _ptr(im), _ptr(imean),
                                              _ptr(ia), _ptr(io), _ptr(ic), im.numel(), _ptr(sid), jitter_rel, _ptr(quad),
                                              _ptr(logdet), _ptr(info), _stream()), "score_groups")
     return quad, logdet, info
 
 
 def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=1e-8, want_logdet=False, want_info=True,
-               symmetric=False):
+               symmetric=False, strides=None):
     """a6 for member segments: segment i against its own state.  Y [n,T]; mean [S,T]; Sigma [S,T,T]; seg_* [n].
     symmetric=True promises Sigma == Sigma^T exactly (upper triangle read only)."""
     Y = _dev64(Y, "Y")
-    Sigma = _dev64(Sigma, "Sigma")
     dev = Y.device
     n, T = Y.shape
-    if mean is not None:
-        mean = _dev64(mean.reshape(-1, T), "mean")
+    if strides is None:
+        Sigma = _dev64(Sigma, "Sigma")
+        if mean is not None:
+            mean = _dev64(mean.reshape(-1, T), "mean")
+    mstride, sstride = (T, T * T) if strides is None else (int(strides[0]), int(strides[1]))
 
     def up(a, dt):
         if a is None:
@@ -156,11 +174,11 @@ def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=
     if T > 128:   # cooperative kernels: one work item (one workgroup) per segment
         ar = torch.arange(n, dtype=torch.int32, device=dev)
         return score_groups(Y, mean, Sigma, sm, sa, ar, torch.ones(n, dtype=torch.int32, device=dev), jitter_rel=jitter_rel,
-                            want_logdet=want_logdet, want_info=want_info, item_mean=sme)
+                            want_logdet=want_logdet, want_info=want_info, item_mean=sme, strides=strides)
     quad = torch.zeros(n, dtype=torch.float64, device=dev)
     logdet = torch.zeros(n, dtype=torch.float64, device=dev) if want_logdet else None
     info = torch.zeros(n, dtype=torch.int32, device=dev) if want_info else None
-    _ffi.check(_ffi.lib.hgp_score_each_f64(_ptr(Y), T, _ptr(mean), T, _ptr(Sigma), T * T, T, _ptr(sm), _ptr(sme), _ptr(sa), n,
+    _ffi.check(_ffi.lib.hgp_score_each_f64(_ptr(Y), T, _ptr(mean), mstride, _ptr(Sigma), sstride, T, _ptr(sm), _ptr(sme), _ptr(sa), n,
                                            jitter_rel, int(bool(symmetric)), _ptr(quad), _ptr(logdet), _ptr(info), _stream()),
                "score_each")
     return quad, logdet, info

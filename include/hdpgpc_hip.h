@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HGP_ABI_VERSION 5   /* 5: + hgp_pairs_plan_set_score_output, hgp_debug_exp_neg_f64; 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path), assignment tail, warp fit, member-step lists; 4: + batched chain gather / finish */
+#define HGP_ABI_VERSION 6   /* 6: + hgp_chol_inverse_ws_f64, candidate / no-smoother flags of the chain finish; 5: + hgp_pairs_plan_set_score_output, hgp_debug_exp_neg_f64; 3: + hgp_pairs_plan_set_accuracy (solve-based per-pair path), assignment tail, warp fit, member-step lists; 4: + batched chain gather / finish */
 /* largest T (basis length) and T* (segment length) served by the register-resident wave kernels */
 #define HGP_MAX_T_WAVE 128
 /* largest T served at all: 128 < T <= 256 runs on cooperative kernels (one workgroup of 4-8 waves per matrix / pair) */
@@ -60,6 +60,10 @@ int hgp_potrf_batched_f64(double* A, int T, int b, double jitter_rel, double add
  * (GPI.py:144-145,267,295; GPI_model.py:1316,1330): S^{-1} = Linv^T Linv. */
 int hgp_chol_inverse_batched_f64(const double* A, int T, int b, double jitter_rel, double add_diag, double* Linv,
                                  int32_t* info, void* stream);
+/* The same with a caller-provided workspace work[b,T,T] (used for T > 128 only; NULL = none): large batches factor every matrix
+ * ONCE into the workspace and take L^-1 from L by block columns instead of one factorisation per block column. */
+int hgp_chol_inverse_ws_f64(const double* A, int T, int b, double jitter_rel, double add_diag, double* Linv, double* work,
+                            int32_t* info, void* stream);
 
 /* a4 + a6 - GPI_model._gaussian_score_shared_cov (GPI_model.py:92-113) over the groups that
  * GPI_model.compute_sq_err_all builds on a shared grid (GPI_model.py:516-533).
@@ -259,7 +263,7 @@ typedef struct hgp_chain_gather_desc {
   const double* st[8];   /* stacks A, G, C, S, Psm, P ([L,T,T]), F, Fsm ([L,T]) */
   const int64_t* pos;
   double* out;           /* [6 T T + 2 T] */
-  const double* Y;       /* observations of the run, row pos - y_row0 is read */
+  const double* Y;       /* observations of the run, row pos - y_row0 is read (y_row0 < 0: row 0, Y is the observation) */
   double* y_out;
   const double* W;       /* [3,2,T,T] means, right covariances, scales of the two MNIW distributions */
   double* Rp;            /* [2,T,T] */
@@ -275,8 +279,13 @@ typedef struct hgp_chain_finish_desc {
   double* stA; double* stG; double* stC; double* stS; double* stF; double* stFsm; double* stP; double* stPsm;
   int64_t* pos;
   int32_t* sync;
-  int T, annealing;
+  int T, annealing;      /* annealing: bit 0 = annealed scales (GPI_model.py:1083-1091); bit 1 = candidate step (new rows are
+                          * written at pos + 1, W / n0 / Nf / pos unchanged); bit 2 = previous smoothed state not rewritten */
 } hgp_chain_finish_desc;
+/* A device-resident list of plain copies dst[0..n) = src[0..n) run as ONE launch (the online step gathers the inputs of its
+ * batched a8 / a9 calls from rows of many clusters' stacks).  max_n = the largest n of the list. */
+typedef struct hgp_copy_item { const double* src; double* dst; long n; } hgp_copy_item;
+int hgp_copy_list_f64(const hgp_copy_item* items_dev, int n_items, long max_n, void* stream);
 int hgp_lds_chain_gather2_batched_f64(const hgp_chain_gather_desc* descs_dev, int n_chains, int T, void* stream);
 int hgp_lds_chain_finish2_batched_f64(const hgp_chain_finish_desc* descs_dev, int n_chains, int T, void* stream);
 /* a10 helper - || G^{-1} y ||^2 for the lower triangle G of a [T, ld] matrix.  IterativeGaussianProcess.

@@ -719,8 +719,11 @@ def gen_include_batch(tag, rec, n=None, lead=0, n_explore=5, leads=None, warp=Fa
             out["ref_sens"] = np.array(max([rel(a[1:3], b[1:3]) for a, b in zip(e2, elbo)] + [rel(a[3:], b[3:]) for a, b in zip(f2, fpw)] +
                                            [max(rel(a[1], b[1]), rel(a[2], b[2])) for a, b in zip(em2, em)]))
             print("reference sensitivity of the traced numbers to a 1e-15 input perturbation:", float(out["ref_sens"]))
-    if n is None or n > 500:          # the full record's beats are already a fixture (mitbih100_lead0.npz)
+    if n is None or n > 500:          # the full record's beats are their own fixture (mitbih<rec>_lead0.npz)
         del out["y"]
+        beats = os.path.join(OUT, f"mitbih{rec}_lead{lead}.npz")
+        if D == 1 and not os.path.exists(beats):
+            np.savez_compressed(beats, y=data[..., 0], labels=np.load(os.path.join(REF, "data", "mitbih", f"{rec}_labels.npy")))
     np.savez_compressed(os.path.join(OUT, f"include_batch_{tag}.npz"), **out)
     print(f"include_batch_{tag}: N={N} wall={wall:.1f}s EM iterations={len(em)} M={sw.M} counts={out['counts_final']} "
           f"events={len(order)} elbo={out['train_elbo']}")
@@ -860,6 +863,8 @@ if __name__ == "__main__":
         gen_include_batch("r102_2leads_n100", "102", 100, leads=(0, 1), n_explore=5)
     if "ib100" in which:
         gen_include_batch("r100", "100", None)
+    if "ib102" in which:              # BASELINE configs[2]: the whole of record 102 (hdpgpc/tests/test_offline.py:32-79)
+        gen_include_batch("r102", "102", None)
     if "learn" in which:
         gen_cluster_learning("r102_2leads", "102", 300, 20)
     if "online90" in which:

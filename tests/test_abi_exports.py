@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 @pytest.mark.skipif(not os.path.exists(LIB), reason="library not built (run __graft_entry__.build())")
 def test_ctypes_binding_loads_without_a_gpu():
     from hdpgpc_amd import _ffi
-    assert _ffi.lib.hgp_abi_version() == 5
+    assert _ffi.lib.hgp_abi_version() == 6
     assert set(_ffi.EXPORTS) == set(header_symbols())
     # argument validation happens before any HIP call
     assert _ffi.lib.hgp_gram_rbf_f64(None, 4, None, 4, 1.0, 1.0, 0.0, None, None) == -1

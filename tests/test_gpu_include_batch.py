@@ -47,6 +47,23 @@ def test_include_batch_r100_full():
     print(f"include_batch, record 100: {wall:.1f} s (reference on 8 vCPU: {float(g['wall_s']):.0f} s), worst relative error {worst:.2e}")
 
 
+def test_include_batch_r102_full():
+    """BASELINE configs[2]: the whole of record 102, lead 0 (2 187 beats, T = 90) as hdpgpc/tests/test_offline.py:32-79 drives it
+    (make_golden.py ib102: 486 traced calls, 10 EM iterations) - final counts [2009, 113, 37, 14, 6, 4, 3, 1] as SURVEY.md section 6
+    reports for the reference; every decision identical."""
+    g = golden("include_batch_r102.npz")
+    y = golden("mitbih102_lead0.npz")["y"]
+    torch.cuda.synchronize()
+    t0 = time.time()
+    sw, tr = run_traced(g, y)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    worst = compare_trace(g, sw, tr, q_tol=1e-7)
+    assert [len(m.indexes) for m in sw.gpmodels[0]] == [2009, 113, 37, 14, 6, 4, 3, 1]
+    print(f"include_batch, record 102: {wall:.1f} s (reference on 8 vCPU: {float(g['wall_s']):.0f} s, SURVEY: 348 s), "
+          f"{len(tr['order'])} traced calls, worst relative error {worst:.2e}")
+
+
 def test_print_results_after_include_batch(capsys):
     from hdpgpc.util_plots import print_results
     g = golden("include_batch_r100_n80.npz")
