@@ -33,6 +33,17 @@ f64 = torch.float64
 _HDP_HYP = {"less": (0.01, 0.01, 0.01, 0.0), "balanced": (1.0, 1.0, 0.1, 0.0), "more": (10.0, 10.0, 1.0, 0.0)}
 
 
+def _limit_host_threads():
+    """The host side of this package only ever touches SMALL CPU tensors (one-hot tables, counts, K x K HDP terms); PyTorch's
+    intra-op pool (one thread per core: 128 on an MI355X host) turns each of those 30 us operations into 0.2 - 1 ms of thread
+    wake-ups (measured: tools/bench_host_ops.py).  One thread for CPU tensor ops unless HGP_HOST_THREADS says otherwise
+    (0 = leave PyTorch's setting alone)."""
+    import os
+    n = int(os.environ.get("HGP_HOST_THREADS", "1"))
+    if n > 0 and torch.get_num_threads() != n:
+        torch.set_num_threads(n)
+
+
 def _first(v):
     """Per-cluster options may arrive as one value or as a list with one value per initial cluster (GPI_HDP.py:123-156)."""
     return v[0] if isinstance(v, (list, np.ndarray)) and np.ndim(v) > 0 else v
@@ -53,6 +64,7 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
             raise NotImplementedError("explicit kernel objects: pass ini_outputscale / ini_lengthscale / bound_sigma instead")
         if inducing_points or estimation_limit is not None:
             raise NotImplementedError("inducing points / estimation_limit are not part of this build")
+        _limit_host_threads()
         self.M = 1 if M is None else int(M)
         self.n_outputs = int(n_outputs)
         self.verbose = verbose

@@ -419,6 +419,29 @@ class GPI_model:
         _, _, C, Sigma = self.get_params(t)
         return f_aux, c_aux, C, Sigma
 
+    def estimate_new_and_include(self, index, x_train, y):
+        """GPI_HDP.estimate_new (GPI_HDP.py:2830-2842) followed by include_weighted_sample(h = 1) of the SAME segment, as the
+        online step does for its would-be new cluster (GPI_HDP.py:1990-1996).  The reference runs the Kalman update twice - from
+        the last filtered state for the score, from the last smoothed state for the inclusion; on a model without history
+        (after reinit_GP) both start from the same prior and take the same first-step branch, so one update serves both.
+        Returns the score."""
+        x = self.cond_to_torch(x_train).reshape(-1, 1)
+        fresh = (self.N == 0 and self.fitted and len(self.f_star) == 1 and self.f_star[0] is self.f_star_sm[0]
+                 and x.shape == self.x_basis.shape and bool(torch.equal(x, self.x_basis)))
+        if not fresh:
+            mean_, cov_, C_, Sigma_ = self.smoother_weighted(x, y, 1.0)
+            score = self.log_sq_error(x, y, mean=mean_[-1], cov=cov_[-1], C=C_[-1], Sigma=Sigma_[-1], i=-1, first=len(self.indexes) == 1)
+            self.include_weighted_sample(index, x, x, y, 1.0)
+            return score
+        f, c = self.posterior_weighted(x, y, 1.0)
+        score = self.log_sq_error(x, y, mean=f, cov=c, C=self.C[-1], Sigma=self.Sigma[-1], i=-1, first=len(self.indexes) == 1)
+        self.N += 1
+        self.indexes.append(int(index))
+        self.x_train.append(x)
+        self.y_train.append(self.cond_to_torch(y).reshape(-1, 1))
+        self.f_star.append(f), self.f_star_sm.append(f), self.cov_f.append(c), self.cov_f_sm.append(c)
+        return score
+
     def reinit_GP(self, save_last=False, save_index=False):
         """GPI_model.py:408-434: drop the filtered / smoothed history (keep the first entry, or first and last)."""
         if save_last:
@@ -1103,15 +1126,29 @@ class GPI_model:
     def compute_q_lat_all(self, x_trains, h_ini=1.0):
         """GPI_model.py:549-559: all members of the cluster in one batch."""
         n = x_trains.shape[0]
-        out = torch.zeros(n, dtype=f64, device=self.device)
-        if self.N == 0 or not bool(torch.any(self.Gamma[-1] != 0)):
-            return out
+        if self.N == 0 or not self._is_dynamic():
+            return torch.zeros(n, dtype=f64, device=self.device)
         ent = self._stk.get("_lat_all")          # members' scores are kept until the model changes (the online loop asks every
         key = (h_ini, len(self.indexes), len(self.Gamma), self.f_star_sm[-1].data_ptr(), self.cov_f_sm[-1].data_ptr())
         if ent is None or ent[0] != key:         # cluster for them at every beat, GPI_HDP.py:1972; only one cluster changes)
             ent = self._stk["_lat_all"] = (key, self._lat_all(h_ini))
-        out[torch.as_tensor(self.indexes, device=self.device)] = ent[1]
-        return out
+        # ... and so is the column itself (zeros with the members' scores scattered in), with room to grow: while the model does
+        # not change, a longer history only needs a longer view of it
+        col = self._stk.get("_lat_col")
+        if col is None or col[0] is not ent[1] or col[1].shape[0] < n:
+            buf = torch.zeros(max(64, 2 * n), dtype=f64, device=self.device)
+            buf[torch.as_tensor(self.indexes, device=self.device)] = ent[1]
+            col = self._stk["_lat_col"] = (ent[1], buf)
+        return col[1][:n]
+
+    def _is_dynamic(self):
+        """bool(any(Gamma[-1] != 0)) (GPI_model.py:551), looked up once per state of the list (a device round trip otherwise)."""
+        G = self.Gamma[-1]
+        key = (len(self.Gamma), G.data_ptr())
+        ent = getattr(self, "_dyn", None)
+        if ent is None or ent[0] != key:
+            ent = self._dyn = (key, bool(torch.any(G != 0)))
+        return ent[1]
 
     # ------------------------------------------------------------------ a9
     def return_LDS_param_likelihood(self, first=False):

@@ -53,6 +53,7 @@ def _load():
         "hgp_chol_rank1_f64": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
         "hgp_trsv_lower_quad_f64": (i32, [vp, i32, vp, i32, vp, vp]),
         "hgp_hmm_messages_f64": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+        "hgp_hmm_local_terms_f64": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "hgp_loglik_rows_f64": (i32, [vp, i32, i32, vp, vp, vp]),
         "hgp_assign_f64": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "hgp_warp_batch_f64": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp, vp, vp]),

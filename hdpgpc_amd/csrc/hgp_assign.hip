@@ -14,6 +14,9 @@ namespace {
 __global__ __launch_bounds__(1024) void k_loglik_rows(const double* __restrict__ q, int N, int K, double* __restrict__ out,
                                                       double* __restrict__ rowmax) {
   __shared__ int any_inf;
+  q += (size_t)blockIdx.x * N * K;            // blockIdx.x = variant of a batch (the rule below is per score matrix)
+  out += (size_t)blockIdx.x * N * K;
+  if (rowmax) rowmax += (size_t)blockIdx.x * N;
   if (threadIdx.x == 0) any_inf = 0;
   __syncthreads();
   int bad = 0;
@@ -62,7 +65,26 @@ __global__ __launch_bounds__(256) void k_assign(const double* __restrict__ fmsg,
     for (int k = 0; k < K; ++k) resp[(size_t)n * K + k] = (k == best) ? 1.0 : 0.0;
 }
 
+// last_log[v, k] = log(fmsg[v, N-1, k] * bmsg[v, N-1, k]) (what variational_local_terms hands back for the newest segment)
+__global__ __launch_bounds__(64) void k_last_log(const double* __restrict__ fmsg, const double* __restrict__ bmsg, int N, int K,
+                                                 double* __restrict__ out) {
+  const size_t o = ((size_t)blockIdx.x * N + (N - 1)) * K;
+  for (int k = threadIdx.x; k < K; k += 64) out[(size_t)blockIdx.x * K + k] = log(fmsg[o + k] * bmsg[o + k]);
+}
+
 }  // namespace
+
+int hgp_internal_loglik_rows_b(const double* q, int N, int K, int B, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_loglik_rows, dim3(B), dim3(1024), 0, st, q, N, K, out, (double*)nullptr);
+  return launch_status();
+}
+
+int hgp_internal_assign_b(const double* fmsg, const double* bmsg, int N, int K, int B, int64_t* labels, double* last_log, hipStream_t st) {
+  const long rows = (long)N * B;
+  hipLaunchKernelGGL(k_assign, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, fmsg, bmsg, (int)rows, K, labels, (double*)nullptr);
+  if (last_log) hipLaunchKernelGGL(k_last_log, dim3(B), dim3(64), 0, st, fmsg, bmsg, N, K, last_log);
+  return launch_status();
+}
 
 extern "C" {
 

@@ -74,6 +74,10 @@ int hgp_internal_pairs_acc(const hgp_pairs_plan* p, const double* x, const doubl
                            const int32_t* sel, double* out_quad, double* out_logdet, int32_t* out_info, hipStream_t st);
 size_t hgp_internal_acc_bytes(int TP, int K, size_t* sizes /*[6]*/);
 
+// hgp_assign.hip: batched LogLik normalisation / arg-max of the state posterior (B score matrices [N, K] back to back)
+int hgp_internal_loglik_rows_b(const double* q, int N, int K, int B, double* out, hipStream_t st);
+int hgp_internal_assign_b(const double* fmsg, const double* bmsg, int N, int K, int B, int64_t* labels, double* last_log, hipStream_t st);
+
 // hgp_matlik.hip: fused one-wave-per-item kernels of a8 / a9 (T <= HGP_MAX_T_WAVE)
 int hgp_internal_lat_error_wave(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* covprev,
                                 int T, int b, double* out, int32_t* info, hipStream_t st);

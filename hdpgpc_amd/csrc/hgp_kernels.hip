@@ -1336,6 +1336,13 @@ __global__ __launch_bounds__(64) void k_hmm_messages(HmmArgs a) {
   double* P = sm;            // [K][K+1]
   double* f = P + K * LD;    // [K]
   const bool fwd = blockIdx.x == 0;
+  {                          // blockIdx.y = variant of a batch of score matrices sharing log_pi / log_trans
+    const size_t vo = (size_t)blockIdx.y * N * K;
+    a.q += vo;
+    a.fmsg += vo;
+    a.bmsg += vo;
+    a.marg += (size_t)blockIdx.y * N;
+  }
   const bool live = i < K;
   const double ninf = -__builtin_inf();
   // my row of the transition operator: forward uses safe_exp(log_trans^T) clamped at 1e-6, backward safe_exp(log_trans)
@@ -1450,6 +1457,82 @@ __global__ __launch_bounds__(256) void k_hmm_pair(const double* __restrict__ q, 
     const int i = e / K, j = e % K;
     o[e] = log(alpha[(size_t)(t - 1) * K + i] * soft[j] * hmm_exp(log_trans[e], rmax[i]) / den);
   }
+}
+
+// The same table reduced on the spot to what the hard assignment keeps of it: the FIRST arg-max of row t over the flattened
+// K x K entries (GPI_HDP._safe_exp on the pair table; row 0 is all -inf -> 0; a row holding a NaN -> 0, as the host layer's
+// first-arg-max did).  Same arithmetic, element by element, as k_hmm_pair; grid (N, variants).
+__global__ __launch_bounds__(256) void k_hmm_pair_first(const double* __restrict__ q_all, const double* __restrict__ log_trans,
+                                                        const double* __restrict__ alpha_all, const double* __restrict__ beta_all,
+                                                        int N, int K, int64_t* __restrict__ first_all) {
+  extern __shared__ double sm[];
+  double* soft = sm;
+  double* rmax = soft + K;
+  __shared__ double red[256];
+  __shared__ int redi[256];
+  __shared__ int any_nan;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const size_t vo = (size_t)blockIdx.y * N * K;
+  const double* q = q_all + vo;
+  const double* alpha = alpha_all + vo;
+  const double* beta = beta_all + vo;
+  int64_t* first = first_all + (size_t)blockIdx.y * N;
+  if (t == 0) {
+    if (tid == 0) first[0] = 0;
+    return;
+  }
+  if (tid == 0) any_nan = 0;
+  double qm = -__builtin_inf();
+  for (int j = 0; j < K; ++j) qm = fmax(qm, q[(size_t)t * K + j]);
+  for (int j = tid; j < K; j += 256) {
+    soft[j] = hmm_exp(q[(size_t)t * K + j], qm) * beta[(size_t)t * K + j];
+    double m = -__builtin_inf();
+    for (int l = 0; l < K; ++l) m = fmax(m, log_trans[(size_t)j * K + l]);
+    rmax[j] = m;
+  }
+  __syncthreads();
+  double s = 0.0;
+  for (int e = tid; e < K * K; e += 256) {
+    const int i = e / K, j = e % K;
+    s += alpha[(size_t)(t - 1) * K + i] * soft[j] * hmm_exp(log_trans[e], rmax[i]);
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  double den = red[0];
+  if (den == 0.0) den = 1e-10;
+  __syncthreads();
+  double bv = -__builtin_inf();
+  int bi = K * K;                       // K * K = "nothing yet": an all -inf row keeps index 0 below
+  bool nan = false;
+  for (int e = tid; e < K * K; e += 256) {
+    const int i = e / K, j = e % K;
+    const double v = log(alpha[(size_t)(t - 1) * K + i] * soft[j] * hmm_exp(log_trans[e], rmax[i]) / den);
+    nan |= (v != v);
+    if (v > bv || (bi == K * K && v == bv)) {
+      bv = v;
+      bi = e;
+    }
+  }
+  if (nan) atomicOr(&any_nan, 1);
+  red[tid] = bv;
+  redi[tid] = bi;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) {
+      const double ov = red[tid + w];
+      const int oi = redi[tid + w];
+      if (ov > red[tid] || (ov == red[tid] && oi < redi[tid])) {
+        red[tid] = ov;
+        redi[tid] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) first[t] = (any_nan || redi[0] >= K * K) ? 0 : redi[0];
 }
 
 // ------------------------------------------------------------------ per-cluster operators (plan)
@@ -2096,6 +2179,23 @@ int hgp_hmm_messages_f64(const double* q, const double* log_pi, const double* lo
   if (log_resp_pair)
     hipLaunchKernelGGL(k_hmm_pair, dim3(N), dim3(256), sizeof(double) * 2 * K, st, q, log_trans, (const double*)fmsg,
                        (const double*)bmsg, N, K, log_resp_pair);
+  return launch_status();
+}
+
+int hgp_hmm_local_terms_f64(const double* q, const double* log_pi, const double* log_trans, int N, int K, int B, double* qnorm,
+                            double* fmsg, double* marg, double* bmsg, int64_t* labels, int64_t* pair_first, double* last_log,
+                            void* stream) {
+  if (N == 0 || B == 0) return 0;
+  if (!q || !log_pi || !log_trans || !qnorm || !fmsg || !marg || !bmsg || !labels || N < 0 || K <= 0 || B < 0) return -1;
+  if (K > 64) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = hgp_internal_loglik_rows_b(q, N, K, B, qnorm, st)) return rc;
+  HmmArgs a{qnorm, log_pi, log_trans, N, K, fmsg, marg, bmsg};
+  hipLaunchKernelGGL(k_hmm_messages, dim3(2, B), dim3(64), sizeof(double) * ((size_t)K * (K + 1) + K), st, a);
+  if (int rc = hgp_internal_assign_b(fmsg, bmsg, N, K, B, labels, last_log, st)) return rc;
+  if (pair_first)
+    hipLaunchKernelGGL(k_hmm_pair_first, dim3(N, B), dim3(256), sizeof(double) * 2 * K, st, (const double*)qnorm, log_trans,
+                       (const double*)fmsg, (const double*)bmsg, N, K, pair_first);
   return launch_status();
 }
 

@@ -12,7 +12,7 @@ import warnings
 
 import numpy as np
 import scipy.optimize
-from scipy.special import digamma, gammaln, polygamma
+from scipy.special import digamma, gammaln, zeta
 
 EPS = 1e-8
 
@@ -50,11 +50,16 @@ def calc_theta_full(trans_count, start_count, M, rho, trans_alpha, start_alpha, 
 
 
 def _objective(rhoomega, T_vec, n_doc, gamma, kappa, K):
-    """Negative surrogate ELBO in (rho, omega) and its gradient."""
+    """Negative surrogate ELBO in (rho, omega) and its gradient.  (One call of each special function on the concatenated
+    arguments, no Python loop over the sticks: the online step runs this optimisation four times per beat and ~20 evaluations
+    per run - at K = 20 the evaluation was 0.1 ms of NumPy call overhead.)"""
     rho, omega = rhoomega[:K], rhoomega[K:]
     g1, g0 = rho * omega, (1.0 - rho) * omega
-    dg_omega = digamma(omega)
-    e_log_u, e_log_1mu = digamma(g1) - dg_omega, digamma(g0) - dg_omega
+    args = np.concatenate((omega, g1, g0))
+    dg = digamma(args)
+    tri = zeta(2.0, args)                       # polygamma(1, x) = zeta(2, x): what scipy.special.polygamma evaluates
+    dg_omega = dg[:K]
+    e_log_u, e_log_1mu = dg[K:2 * K] - dg_omega, dg[2 * K:] - dg_omega
     kv = np.arange(K, 0, -1, dtype=np.float64)
     if kappa > 0:
         scale = 1.0
@@ -62,18 +67,20 @@ def _objective(rhoomega, T_vec, n_doc, gamma, kappa, K):
     else:
         scale = float(n_doc)
         on, off = 1.0 + (1.0 - g1) / scale, kv + (gamma - g0) / scale
-    ebeta = rho2beta(rho)
-    c_beta = np.sum(gammaln(g1 + g0) - gammaln(g1) - gammaln(g0))
-    elbo = -c_beta / scale + on @ e_log_u + off @ e_log_1mu + ebeta @ T_vec
-    tri_o, tri_1, tri_0 = polygamma(1, omega), polygamma(1, g1), polygamma(1, g0)
-    g_rho = on * omega * tri_1 - off * omega * tri_0
-    g_omega = on * (rho * tri_1 - tri_o) + off * ((1.0 - rho) * tri_0 - tri_o)
+    one_m = 1.0 - rho
+    ebeta = np.empty(K + 1)
+    ebeta[:K] = rho
+    ebeta[K] = 1.0
+    ebeta[1:] *= np.cumprod(one_m)
+    gl = gammaln(np.concatenate((g1 + g0, g1, g0)))
+    c_beta = np.sum(gl[:K] - gl[K:2 * K] - gl[2 * K:])
+    w = ebeta * T_vec
+    elbo = -c_beta / scale + on @ e_log_u + off @ e_log_1mu + np.sum(w)
+    tri_o, tri_1, tri_0 = tri[:K], tri[K:2 * K], tri[2 * K:]
     # d E[beta_j] / d rho_k: E[beta_k] / rho_k on the diagonal, -E[beta_j] / (1 - rho_k) for j > k
-    delta = np.zeros((K, K + 1))
-    for k in range(K):
-        delta[k, k] = ebeta[k] / rho[k]
-        delta[k, k + 1:] = -ebeta[k + 1:] / (1.0 - rho[k])
-    g_rho = g_rho + delta @ T_vec
+    tail = np.cumsum(w[::-1])[::-1]             # tail[k] = sum_{j >= k} E[beta_j] T_j
+    g_rho = on * omega * tri_1 - off * omega * tri_0 + (w[:K] / rho - tail[1:] / one_m)
+    g_omega = on * (rho * tri_1 - tri_o) + off * (one_m * tri_0 - tri_o)
     return -elbo, -np.concatenate([g_rho, g_omega])
 
 

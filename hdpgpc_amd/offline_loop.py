@@ -161,9 +161,10 @@ class OfflineLoop:
 
     def elbo_Linears(self, resp, respPair, post=False, one_sample=False):
         """GPI_HDP.py:1025-1074: the HDP part of the bound for a given hard assignment."""
-        start = resp[0].numpy().copy()
-        trans = torch.sum(respPair, dim=0).numpy().copy()
-        M = resp.shape[1]
+        return self._elbo_linears_counts(resp[0].numpy().copy(), torch.sum(respPair, dim=0).numpy().copy(), resp.shape[1], post, one_sample)
+
+    def _elbo_linears_counts(self, start, trans, M, post=False, one_sample=False):
+        """elbo_Linears from the counts themselves: start [M] = one-hot of the first assignment, trans [M, M] = pair counts."""
         if start.shape[0] == M:
             start = np.append(start, 0.0)
         if trans.shape[-1] == M:

@@ -36,6 +36,47 @@ _SH4 = ("X4", "RH4", "Z4", "Y4", "WK4")
 _SH2 = ("S__", "S_", "Zs", "Y3", "WK2")
 
 
+class _LevelLists:
+    """The level lists of every slot, level-major in device memory with room for `cap` slots.  All slots have the same item
+    shapes, so the per-tile maps of hgp_gemm_list_mapped_f64 depend on the slot index only and are laid down once for the whole
+    capacity; adopting a cluster uploads that slot's items (one small copy per level) instead of rebuilding every list."""
+
+    def __init__(self, cap, device):
+        self.cap, self.device = cap, device
+        self.per = self.tiles = self.dev = self.map = None
+        self.keep = {}
+
+    def set_slot(self, c, lv):
+        isz = ctypes.sizeof(_ffi.GemmItem)
+        if self.per is None:
+            self.per = [len(l_._items) for l_ in lv]
+            self.tiles = [list(l_._item_tiles) for l_ in lv]
+            self.dev, self.map = [], []
+            for per, tiles in zip(self.per, self.tiles):
+                if self.cap * per > 65535:
+                    raise ValueError("online pool: too many clusters for the 16-bit item index of the tile map")
+                self.dev.append(torch.zeros(self.cap * per * isz, dtype=torch.uint8, device=self.device))
+                one = np.concatenate([(i << 16) | np.arange(n, dtype=np.uint32) for i, n in enumerate(tiles)]).astype(np.uint32)
+                allm = (one[None, :] + ((np.arange(self.cap, dtype=np.uint32) * per) << 16)[:, None]).reshape(-1)
+                self.map.append(torch.from_numpy(allm.view(np.int32)).to(self.device))
+        for l, l_ in enumerate(lv):
+            assert len(l_._items) == self.per[l] and list(l_._item_tiles) == self.tiles[l]
+            arr = (_ffi.GemmItem * self.per[l])(*l_._items)
+            host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+            self.dev[l][c * self.per[l] * isz:(c + 1) * self.per[l] * isz].copy_(host)
+        self.keep[c] = lv                      # the operands' storage must outlive the lists
+
+    def run(self, l, lo, hi):
+        per, tps = self.per[l], sum(self.tiles[l])
+        isz = ctypes.sizeof(_ffi.GemmItem)
+        if lo == 0:
+            _ffi.check(_ffi.lib.hgp_gemm_list_mapped_f64(ops._ptr(self.dev[l]), per * hi, ops._ptr(self.map[l]), tps * hi, ops._stream()),
+                       "gemm_list_mapped")
+        else:
+            base = ctypes.c_void_p(self.dev[l].data_ptr() + lo * per * isz)
+            _ffi.check(_ffi.lib.hgp_gemm_list_f64(base, per * (hi - lo), tps * (hi - lo), ops._stream()), "gemm_list")
+
+
 class _Slot:
     __slots__ = ("g", "ch", "rows", "N", "ini_noise", "def_diag", "bad0")
 
@@ -43,13 +84,13 @@ class _Slot:
 class OnlinePool:
     """All cluster models of one lead of an online GPI_HDP, as persistent chains (see the module docstring)."""
 
-    def __init__(self, T, device, annealing, cap=8):
+    def __init__(self, T, device, annealing, cap=32):
         self.T, self.device, self.annealing = int(T), device, bool(annealing)
         self.slots = []
         self.cap = 0
-        self.merged = None
-        self._alloc(cap)
         self.ybuf = torch.zeros((1, T), dtype=f64, device=device)
+        self._pending = None
+        self._alloc(cap)
 
     # ------------------------------------------------------------------ storage
     def _alloc(self, cap):
@@ -66,7 +107,11 @@ class OnlinePool:
         self.bad_all = torch.zeros((cap, 2), dtype=torch.int32, device=dev)      # committed steps
         self.badc_all = torch.zeros((cap, 2), dtype=torch.int32, device=dev)     # candidate steps (cleared per beat)
         self.sync_all = torch.zeros(cap, dtype=torch.int32, device=dev)
-        self.est_mean = new(cap, T)
+        self.est_mean, self.mean_last = new(cap, T), new(cap, T)
+        self.lists = _LevelLists(cap, dev)
+        self.descs_dirty = True
+        self._base = np.zeros((cap, 8), dtype=np.int64)        # byte addresses of the stacks / step buffers of every slot
+        self._bufp = np.zeros((cap, 3), dtype=np.int64)
         # inputs of the batched a8 (three members per cluster) and a9 (two parameter pairs per cluster) calls
         self.LF_cur, self.LF_prev = new(cap * 3, T), new(cap * 3, T)
         self.LA, self.LG, self.LC = new(cap * 3, T, T), new(cap * 3, T, T), new(cap * 3, T, T)
@@ -79,7 +124,6 @@ class OnlinePool:
         self._alloc(self.cap * 2)
         for sl in old:
             self._bind(sl)
-        self.merged = None
 
     def _views(self, c):
         v = {k: self.shared[k][4 * c:4 * c + 4] for k in ("X4", "RH4", "Z4", "Y4", "i4")}
@@ -98,6 +142,12 @@ class OnlinePool:
         T, tt = self.T, self.T * self.T
         Cw = ch["ws"][2 * tt:3 * tt].view(T, T)
         ch["lv"][6].add(Cw, ch["bufs"]["f_post"], self.est_mean[c])          # C_last f_post: the mean estimate_new scores against
+        lvm = ops.GemmList(self.device)                                      # C_last f_last: the mean the beat is scored against
+        lvm.add(Cw, ch["ws"][6 * tt:6 * tt + T], self.mean_last[c])
+        self.lists.set_slot(c, ch["lv"] + [lvm])
+        self._base[c] = [ch[k].data_ptr() for k in _STACKS]
+        self._bufp[c] = [ch["bufs"][k].data_ptr() for k in ("f_post", "f_sm_prev", "P_sm_prev")]
+        self.descs_dirty = True
         dd = sl.g
         self.MN_mean[2 * c].copy_(dd.C_def), self.MN_mean[2 * c + 1].copy_(dd.A_def)
         self.MN_scale[2 * c].copy_(dd.Sigma_def), self.MN_scale[2 * c + 1].copy_(dd.Gamma_def)
@@ -143,7 +193,6 @@ class OnlinePool:
         sl.bad0 = 0
         self._bind(sl)
         self._rebind_lists(sl, float(mi.n0))
-        self.merged = None
         return sl
 
     def _rebind_lists(self, sl, n0):
@@ -154,7 +203,7 @@ class OnlinePool:
         W = ch["W"]
         g.internal_params = matrix_normal_inv_wishart(W[0, 0], W[1, 0], n0, W[2, 0])
         g.observation_params = matrix_normal_inv_wishart(W[0, 1], W[1, 1], n0, W[2, 1])
-        g._stk = {k: v for k, v in g._stk.items() if k in ("_lat_all",)}
+        g._stk = {k: v for k, v in g._stk.items() if k in ("_lat_all", "_lat_col")}
 
     def _more_rows(self, sl):
         ch = sl.ch
@@ -168,11 +217,13 @@ class OnlinePool:
         self._rebind_lists(sl, float(sl.g.internal_params.n0))
         if lat is not None:           # the key holds data pointers of the old stacks
             sl.g._stk["_lat_all"] = (self._lat_key(sl.g), lat[1])
-        self.merged = None
+        self._base[sl.g._slot] = [ch[k].data_ptr() for k in _STACKS]
+        self.descs_dirty = True
 
     # ------------------------------------------------------------------ launch tables
     def _prepare(self):
-        """Descriptor arrays and merged level lists for the current set of slots (rebuilt when a slot is added or moves)."""
+        """Descriptor arrays of the gather / finish launches for the current slots (re-uploaded when a slot is added or its
+        stacks move)."""
         p = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
         T = self.T
         gd, fd_dry, fd_real = [], [], []
@@ -195,24 +246,25 @@ class OnlinePool:
                 lst.append(f)
         from .chain_batch import _descs
         self.gdev, self.fdev_dry, self.fdev_real = _descs(gd, self.device), _descs(fd_dry, self.device), _descs(fd_real, self.device)
-        n_lv = len(self.slots[0].ch["lv"])
-        self.per = [len(self.slots[0].ch["lv"][l]._items) for l in range(n_lv)]
-        self.merged = [ops.GemmList.concat([sl.ch["lv"][l] for sl in self.slots]).finalize() for l in range(n_lv)]
         self.riding = self.slots[0].ch["riding"]
-        # static part of the copy table (base pointers of the stacks and step buffers of every slot)
-        self._base = np.array([[sl.ch[k].data_ptr() for k in _STACKS] for sl in self.slots], dtype=np.int64)
-        self._bufp = np.array([[sl.ch["bufs"][k].data_ptr() for k in ("f_post", "f_sm_prev", "P_sm_prev")] for sl in self.slots],
-                              dtype=np.int64)
+        self.descs_dirty = False
 
-    def _step(self, lo, hi, dry):
-        """The member step of slots [lo, hi): one launch per dependency level (GPI_model._chain_step2 for many chains)."""
-        if self.merged is None:
+    def _gather(self, lo, hi):
+        if self.descs_dirty:
             self._prepare()
-        T, k, sh, per, mg = self.T, hi - lo, self.shared, self.per, self.merged
-        gsz, fsz = ctypes.sizeof(_ffi.ChainGatherDesc), ctypes.sizeof(_ffi.ChainFinishDesc)
-        st = ops._stream
-        _ffi.check(_ffi.lib.hgp_lds_chain_gather2_batched_f64(ctypes.c_void_p(self.gdev.data_ptr() + lo * gsz), k, T, st()), "chain_gather2_batched")
-        run = lambda l: mg[l].run_range(per[l] * lo, per[l] * k)        # noqa: E731
+        gsz = ctypes.sizeof(_ffi.ChainGatherDesc)
+        _ffi.check(_ffi.lib.hgp_lds_chain_gather2_batched_f64(ctypes.c_void_p(self.gdev.data_ptr() + lo * gsz), hi - lo, self.T, ops._stream()),
+                   "chain_gather2_batched")
+
+    def _step(self, lo, hi, dry, gather=True):
+        """The member step of slots [lo, hi): one launch per dependency level (GPI_model._chain_step2 for many chains)."""
+        if self.descs_dirty:
+            self._prepare()
+        T, k, sh = self.T, hi - lo, self.shared
+        fsz = ctypes.sizeof(_ffi.ChainFinishDesc)
+        if gather:
+            self._gather(lo, hi)
+        run = lambda l: self.lists.run(l, lo, hi)        # noqa: E731
         s4, s2 = slice(4 * lo, 4 * hi), slice(2 * lo, 2 * hi)
         for l in range(4):
             run(l)
@@ -235,24 +287,37 @@ class OnlinePool:
             run(11)
         run(9)
         fdev = self.fdev_dry if dry else self.fdev_real
-        _ffi.check(_ffi.lib.hgp_lds_chain_finish2_batched_f64(ctypes.c_void_p(fdev.data_ptr() + lo * fsz), k, T, st()), "chain_finish2_batched")
+        _ffi.check(_ffi.lib.hgp_lds_chain_finish2_batched_f64(ctypes.c_void_p(fdev.data_ptr() + lo * fsz), k, T, ops._stream()),
+                   "chain_finish2_batched")
 
-    # ------------------------------------------------------------------ candidates
-    def candidates(self, y, t_new, q_lat_cols, indexes):
-        """Every cluster with the beat y [T] added (dry run).  q_lat_cols [T_all, M']: the clusters' current latent-transition
-        columns in SLOT order; indexes[c] = member segment ids of slot c.  Returns
-        (est [M] device: estimate_new's score, cols [T_all, M] device: the candidates' latent-transition columns,
-         lds [M] host floats: return_LDS_param_likelihood of the candidates)."""
+    # ------------------------------------------------------------------ the beat under the clusters' last states
+    def begin_beat(self, y):
+        """Gather every cluster's last state (row pos of its stacks) and score the beat y [T] under it: log_sq_error(x, y, i=-1)
+        of GPI_HDP.py:1973 for all clusters in three launches.  Returns (scores, LAPACK infos) in SLOT order [M] (device); the
+        gathered state stays valid for candidates() of the same beat."""
         M, T = len(self.slots), self.T
         tt = T * T
         for sl in self.slots:
             if sl.N + 2 > sl.rows:
                 self._more_rows(sl)
-        if self.merged is None:
-            self._prepare()
         self.ybuf.copy_(y.reshape(1, T))
+        self._gather(0, M)
+        self.lists.run(len(self.lists.per) - 1, 0, M)          # mean_last = C_last f_last
+        ar = np.arange(M, dtype=np.int32)
+        quad, _, info = ops.score_each(self.ybuf.expand(M, T).contiguous(), self.mean_last, self.ws_all[0, 3 * tt:], ar, ar, None,
+                                       strides=(T, self.WS))
+        return -0.5 * quad - 0.5 * T * LOG2PI, info
+
+    # ------------------------------------------------------------------ candidates
+    def candidates(self, t_new, q_lat_cols, indexes):
+        """Every cluster with the beat of begin_beat(y) added (dry run).  q_lat_cols [T_all, M']: the clusters' current latent-transition
+        columns in SLOT order; indexes[c] = member segment ids of slot c.  Returns
+        (est [M] device: estimate_new's score, cols [T_all, M] device: the candidates' latent-transition columns,
+         lds [M] host floats: return_LDS_param_likelihood of the candidates)."""
+        M, T = len(self.slots), self.T
+        tt = T * T
         self.badc_all[:M].zero_()
-        self._step(0, M, dry=True)
+        self._step(0, M, dry=True, gather=False)               # begin_beat(y) of this beat gathered the state
         # estimate_new: the beat against (C_last f_post, Sigma_last), `first` inflation for one-member clusters
         Y = self.ybuf.expand(M, T).contiguous()
         add = np.array([sl.ini_noise if sl.N == 1 else 0.0 for sl in self.slots])
@@ -262,7 +327,7 @@ class OnlinePool:
         # a8 / a9 inputs by ONE copy-list launch.  Rows: N = members so far = index of the last row; N + 1 = the dry run's row
         N = np.array([sl.N for sl in self.slots], dtype=np.int64)
         one = N == 1
-        base, bufp = self._base, self._bufp
+        base, bufp = self._base[:M], self._bufp[:M]
         iA, iG, iC, iS, iPsm, iP, iF, iFsm = range(8)
         row = lambda k, r, n: base[:, k] + r * (8 * n)                           # noqa: E731  (byte address of a stack row)
         f_post, f_smp, P_smp = bufp[:, 0], bufp[:, 1], bufp[:, 2]
@@ -325,13 +390,15 @@ class OnlinePool:
         return (h_ini, len(g.indexes), len(g.Gamma), g.f_star_sm[-1].data_ptr(), g.cov_f_sm[-1].data_ptr())
 
     def commit(self, g, index, x_train, y):
-        """include_weighted_sample(h = 1) + bayesian_new_params(1) of the cluster that absorbs the beat (no smoother)."""
+        """include_weighted_sample(h = 1) + bayesian_new_params(1) of the cluster that absorbs the beat (no smoother).  The launches
+        are enqueued and the host-side bookkeeping is done here; the two status words the reference looks at (a failed filter
+        step raises, a failed MNIW factorisation keeps the previous distributions, GPI_model.py:1068) are read by finish_commit(),
+        so that the caller's host work (the HDP global step) overlaps the device work."""
+        self.finish_commit()
         sl = self.slots[g._slot]
         T = self.T
         if sl.N + 2 > sl.rows:
             self._more_rows(sl)
-        if self.merged is None:
-            self._prepare()
         lat_old = g._stk.get("_lat_all")
         if lat_old is not None and lat_old[0] != self._lat_key(g):
             lat_old = None
@@ -339,21 +406,15 @@ class OnlinePool:
         self.ybuf.copy_(yv.reshape(1, T))
         c = g._slot
         self._step(c, c + 1, dry=False)
-        bad = self.bad_all[c].tolist()                       # the reference looks at its LinAlgError here too (GPI_model.py:1068)
-        if bad[1] != 0:
-            raise torch.linalg.LinAlgError("posterior: the input is not positive-definite (online step)")
-        updated = bad[0] == sl.bad0
-        sl.bad0 = bad[0]
-        if not updated and g.verbose:
-            print("Alg error matrix ill conditioned.")
         sl.N += 1
         g.N += 1
         g.indexes.append(int(index))
         g.x_train.append(x_train)
         g.y_train.append(yv)
-        self._rebind_lists(sl, float(g.internal_params.n0) + (1.0 if updated else 0.0))
-        # latent-transition scores: member 0 now reads the new last parameters, the new member is added; the rest is unchanged
+        self._rebind_lists(sl, float(g.internal_params.n0) + 1.0)
+        info = None
         if lat_old is not None:
+            # latent-transition scores: member 0 now reads the new last parameters, the new member is added; the rest is unchanged
             n = sl.N                                          # members now; rows 0..n
             ch = sl.ch
             fs, ps = ch["Fsm"], ch["Psm"]
@@ -362,10 +423,32 @@ class OnlinePool:
             A2, G2 = torch.stack((ch["A"][n], ch["A"][n])), torch.stack((ch["G"][n], ch["G"][n]))
             C2 = torch.stack((ps[1], ps[n - 1]))
             out, info = ops.lat_error(cur, prv, A2, G2, C2)
-            ops.raise_on_info(info, "log_lat_error")
             out = out - 0.5 * T * LOG2PI
             new = torch.cat([out[0:1], lat_old[1][1:], out[1:2]])
             g._stk["_lat_all"] = (self._lat_key(g), new)
+            col = g._stk.get("_lat_col")                       # the scattered column: two entries change
+            if col is not None and col[0] is lat_old[1] and col[1].shape[0] > int(index):
+                col[1][torch.as_tensor([g.indexes[0], int(index)], device=self.device)] = out
+                g._stk["_lat_col"] = (new, col[1])
+        self._pending = (sl, info)
+
+    def finish_commit(self):
+        if self._pending is None:
+            return
+        (sl, info), self._pending = self._pending, None
+        g, c = sl.g, sl.g._slot
+        flat = torch.cat([self.bad_all[c].to(f64)] + ([] if info is None else [info.to(f64)])).tolist()     # one round trip
+        if flat[1] != 0:
+            raise torch.linalg.LinAlgError("posterior: the input is not positive-definite (online step)")
+        if any(flat[2:]):
+            raise torch.linalg.LinAlgError("log_lat_error: the input is not positive-definite (online step)")
+        updated = int(flat[0]) == sl.bad0
+        sl.bad0 = int(flat[0])
+        if not updated:                                        # the MNIW update was skipped: the distributions kept their count
+            if g.verbose:
+                print("Alg error matrix ill conditioned.")
+            g.internal_params.n0 -= 1.0
+            g.observation_params.n0 -= 1.0
 
 
 class CandidateView:

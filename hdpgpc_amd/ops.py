@@ -602,6 +602,23 @@ def hmm_messages(q, log_pi, log_trans, want_pair=True):
     return fmsg, marg, bmsg, pair
 
 
+def hmm_local_terms(Q, log_pi, log_trans, want_pair=True):
+    """The local step of the switching variable for a batch of score matrices Q [B,N,K] sharing log_pi / log_trans
+    (hgp_hmm_local_terms_f64): LogLik normalisation, messages and hard assignment per matrix.  Returns device tensors
+    (labels [B,N] int64, pair_first [B,N] int64 or None, last_log [B,K])."""
+    Q, log_pi, log_trans = _dev64(Q, "Q"), _dev64(log_pi.reshape(-1), "log_pi"), _dev64(log_trans, "log_trans")
+    B, N, K = Q.shape
+    dev = Q.device
+    qn, fm, bm = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+    marg = torch.empty((B, N), dtype=torch.float64, device=dev)
+    labels = torch.empty((B, N), dtype=torch.int64, device=dev)
+    pair = torch.empty((B, N), dtype=torch.int64, device=dev) if want_pair else None
+    last = torch.empty((B, K), dtype=torch.float64, device=dev)
+    _ffi.check(_ffi.lib.hgp_hmm_local_terms_f64(_ptr(Q), _ptr(log_pi), _ptr(log_trans), N, K, B, _ptr(qn), _ptr(fm), _ptr(marg), _ptr(bm),
+                                                _ptr(labels), _ptr(pair), _ptr(last), _stream()), "hmm_local_terms")
+    return labels, pair, last
+
+
 def loglik_rows(q):
     """GPI_HDP.LogLik(axis=1) on the device: (q - rowmax, rowmax); unchanged input if any row maximum is infinite."""
     q = _dev64(q, "q")

@@ -299,6 +299,14 @@ int hgp_trsv_lower_quad_f64(const double* G, int ld, const double* y, int T, dou
  * in GPI_HDP.py:3645), log_resp_pair[N,K,K] (may be NULL; row 0 = -inf as in the reference).  K <= 64 (-2 above). */
 int hgp_hmm_messages_f64(const double* q, const double* log_pi, const double* log_trans, int N, int K, double* fmsg,
                          double* marg, double* bmsg, double* log_resp_pair, void* stream);
+/* The whole local step of the switching variable for a BATCH of B score matrices q[B,N,K] that share log_pi / log_trans (the
+ * online step's candidates, GPI_HDP.py:586-630 once per candidate): LogLik normalisation per matrix -> qnorm[B,N,K], messages
+ * -> fmsg / bmsg [B,N,K], marg [B,N], then the hard assignment: labels[B,N] = first arg-max of log(fmsg * bmsg) per row,
+ * pair_first[B,N] (may be NULL) = first arg-max of the K x K pair table of row n (0 for row 0), last_log[B,K] (may be NULL)
+ * = log(fmsg * bmsg) of the last row.  The [N,K,K] pair table is never written.  K <= 64. */
+int hgp_hmm_local_terms_f64(const double* q, const double* log_pi, const double* log_trans, int N, int K, int B, double* qnorm,
+                            double* fmsg, double* marg, double* bmsg, int64_t* labels, int64_t* pair_first, double* last_log,
+                            void* stream);
 /* SURVEY 8f-3, assignment tail.  hgp_loglik_rows_f64 = GPI_HDP.LogLik(axis=1) (GPI_HDP.py:632-661): out[n,:] = q[n,:] -
  * max_k q[n,k], rowmax[n] (may be NULL) = that maximum; if any row maximum is infinite the input is returned unchanged, as the
  * reference does.  hgp_assign_f64 = GPI_HDP._safe_exp (the one-hot arg-max, GPI_HDP.py:338-343) of log(fmsg * bmsg):

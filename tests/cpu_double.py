@@ -50,7 +50,7 @@ def potrf_batched(A, jitter_rel=1e-8, add_diag=0.0, want_inv=False, want_logdet=
     return tuple(out)
 
 
-def chol_inverse(A, jitter_rel=0.0, add_diag=0.0, out=None, info=None):
+def chol_inverse(A, jitter_rel=0.0, add_diag=0.0, out=None, info=None, work=None):
     L, inf, Z = potrf_batched(A, jitter_rel, add_diag, want_inv=True)
     if out is not None:
         out.copy_(Z)
@@ -82,7 +82,7 @@ def _quad(y, mean, cov, add, jitter_rel):
 
 
 def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids=None, jitter_rel=1e-8, want_logdet=False,
-                 want_info=True, item_mean=None):
+                 want_info=True, item_mean=None, strides=None):
     Yn, Sn = _n(Y), _n(Sigma).reshape(-1, Y.shape[1], Y.shape[1])
     mn = np.zeros((Sn.shape[0], Y.shape[1])) if mean is None else _n(mean).reshape(-1, Y.shape[1])
     quad, info = np.zeros(Yn.shape[0]), np.zeros(Yn.shape[0], dtype=np.int32)
@@ -98,7 +98,7 @@ def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids
 
 
 def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=1e-8, want_logdet=False, want_info=True,
-               symmetric=False):
+               symmetric=False, strides=None):
     Yn, Sn, mn = _n(Y), _n(Sigma), _n(mean).reshape(-1, Y.shape[1])
     sm = _n(seg_mat)
     sme = sm if seg_mean is None else _n(seg_mean)
@@ -130,6 +130,20 @@ def hmm_messages(q, log_pi, log_trans, want_pair=True):
     return _t(fmsg), _t(marg), _t(bmsg), pair
 
 
+def hmm_local_terms(Q, log_pi, log_trans, want_pair=True):
+    labels, pairs, last = [], [], []
+    for b in range(Q.shape[0]):
+        qn = loglik_rows(Q[b])[0]
+        fmsg, _, bmsg, pair = hmm_messages(qn, log_pi, log_trans, True)
+        lg = torch.log(fmsg * bmsg)
+        labels.append(torch.argmax(lg, dim=1))
+        flat = _n(pair).reshape(pair.shape[0], -1)
+        first = np.array([0 if np.isnan(r).any() else int(np.argmax(r)) for r in flat], dtype=np.int64)
+        pairs.append(torch.as_tensor(first))
+        last.append(lg[-1])
+    return torch.stack(labels), torch.stack(pairs), torch.stack(last)
+
+
 def loglik_rows(q):
     c = torch.max(q, dim=1)[0]
     if bool(torch.any(torch.isinf(c))):
@@ -146,6 +160,53 @@ def assign(fmsg, bmsg, want_resp=False):
     return lab, resp
 
 
+class EagerPool:
+    """Stand-in for hdpgpc_amd.online_chain.OnlinePool with the same interface: the candidates and the committed step computed
+    with the one-by-one GPI_model methods (through the stand-ins above), so that the CPU tier exercises the host logic
+    GPI_HDP.include_sample wraps around the pool (slot <-> cluster mapping, cumulative candidate tables, commit)."""
+
+    def __init__(self, T, device, annealing, cap=8):
+        self.slots = []
+
+    @staticmethod
+    def supports(g):
+        return g.N >= 1
+
+    def adopt(self, g):
+        import types
+        g._slot = len(self.slots)
+        self.slots.append(types.SimpleNamespace(g=g))
+
+    def begin_beat(self, y):
+        self._y = y.reshape(-1, 1)
+        sc = torch.stack([sl.g.log_sq_error(sl.g.x_basis, self._y, i=-1) for sl in self.slots])
+        return sc, torch.zeros(len(self.slots), dtype=torch.int32)
+
+    def candidates(self, t_new, q_lat_cols, indexes):
+        import types
+        import hdpgpc_amd.GPI_HDP as H
+        est, cols, lds = [], [], []
+        hist = torch.empty((q_lat_cols.shape[0], 0))
+        for sl in self.slots:
+            cand = H.GPI_HDP.gpmodel_deepcopy(types.SimpleNamespace(verbose=False), sl.g)
+            x, yy = cand.x_basis, self._y
+            mean_, cov_, C_, Sigma_ = cand.smoother_weighted(x, yy, 1.0)
+            est.append(cand.log_sq_error(x, yy, mean=mean_[-1], cov=cov_[-1], C=C_[-1], Sigma=Sigma_[-1], i=-1, first=len(cand.indexes) == 1))
+            cand.include_weighted_sample(t_new, x, x, yy, 1.0)
+            cand.backwards_pair(1.0)
+            cand.bayesian_new_params(1.0)
+            cols.append(cand.compute_q_lat_all(hist, h_ini=1.0))
+            lds.append(cand.lds_param_likelihood_value())
+        return torch.stack(est), torch.stack(cols, dim=1), lds
+
+    def commit(self, g, index, x_train, y):
+        g.include_weighted_sample(index, x_train, x_train, y, 1.0)
+        g.bayesian_new_params(1.0)
+
+    def finish_commit(self):
+        pass
+
+
 def install(monkeypatch):
     """Route the host layer to this file and to CPU tensors for one test."""
     import hdpgpc_amd.GPI_HDP as H
@@ -153,9 +214,11 @@ def install(monkeypatch):
     from hdpgpc_amd import ops
 
     for name in ("gram_rbf", "potrf_batched", "chol_inverse", "gemm_batched", "score_groups", "score_each", "lat_error",
-                 "mniw_loglik", "hmm_messages", "loglik_rows", "assign"):
+                 "mniw_loglik", "hmm_messages", "hmm_local_terms", "loglik_rows", "assign"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(H.GPI_HDP, "_default_device", "cpu")
+    from hdpgpc_amd import online_chain
+    monkeypatch.setattr(online_chain, "OnlinePool", EagerPool)
     torch.set_num_threads(1)                # 90 x 90 products: one thread is 10x faster than eight
     from hdpgpc_amd import chain_batch
     monkeypatch.setattr(chain_batch, "_graphable", lambda job: False)      # no hipGraph chains on the CPU: one pass after the other

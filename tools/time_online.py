@@ -21,6 +21,13 @@ g = np.load(os.path.join(ROOT, "tests", "golden", name))
 run_online(g)                        # warm-up (library load, plan caches)
 torch.cuda.synchronize()
 pr = cProfile.Profile() if "--profile" in sys.argv else None
+if "--nogc" in sys.argv:
+    import gc
+    gc.disable()
+if os.environ.get("HGP_ONLINE_TIMING"):
+    from hdpgpc_amd import online_loop
+    online_loop.TIMING.clear()
+    online_loop._t_last[0] = time.perf_counter()
 t0 = time.perf_counter()
 if pr:
     pr.enable()
@@ -32,5 +39,9 @@ wall = time.perf_counter() - t0
 n = len(tr)
 print(f"include_sample on {n} beats of {name} (T = {g['y'].shape[1]}): {wall:.3f} s = {1e3 * wall / n:.2f} ms per beat; "
       f"clusters at the end {sw.M}; reference {float(g['secs'].sum()):.1f} s")
+if os.environ.get("HGP_ONLINE_TIMING"):
+    from hdpgpc_amd import online_loop
+    print({k: round(1e3 * v / n, 2) for k, v in online_loop.TIMING.items()}, "ms per beat")
 if pr:
-    pstats.Stats(pr).sort_stats("cumtime").print_stats(60)
+    pstats.Stats(pr).sort_stats("cumtime").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(45)
