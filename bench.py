@@ -83,17 +83,16 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def secondary_offline_r100(dev):
-    """BASELINE configs[0] / north_star's wall-clock target: GPI_HDP.include_batch on MIT-BIH record 100, lead 0 (2 272 beats,
-    T = 90), driven as hdpgpc/tests/test_offline.py drives the reference, kernel hyper-parameters injected as in the golden run
-    (the gpytorch fit is not part of either number).  The beats are the committed fixture tests/golden/mitbih100_lead0.npz;
-    the reference's own wall-clock for the same call is stored in tests/golden/include_batch_r100.npz (make_golden.py ib100, this
-    build container's 8 vCPUs; SURVEY.md section 6 measured 119.5 s on an idle container)."""
+def secondary_offline(dev, rec, survey_s, cfg):
+    """GPI_HDP.include_batch on a whole MIT-BIH record, lead 0 (T = 90), driven as hdpgpc/tests/test_offline.py drives the
+    reference, kernel hyper-parameters injected as in the golden run (the gpytorch fit is not part of either number).  The beats are
+    the committed fixture tests/golden/mitbih<rec>_lead0.npz; the reference's own wall-clock for the same call (traced, this build
+    container's 8 vCPUs) is stored in tests/golden/include_batch_r<rec>.npz; SURVEY.md section 6 measured `survey_s` untraced."""
     gdir = os.path.join(ROOT, "tests", "golden")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from offline_trace import run_model
-    g = np.load(os.path.join(gdir, "include_batch_r100.npz"))
-    y = np.load(os.path.join(gdir, "mitbih100_lead0.npz"))["y"]
+    g = np.load(os.path.join(gdir, f"include_batch_r{rec}.npz"))
+    y = np.load(os.path.join(gdir, f"mitbih{rec}_lead0.npz"))["y"]
     times = []
     for _ in range(2):                      # first run includes library / graph warm-up; report both
         torch.cuda.synchronize()
@@ -104,11 +103,64 @@ def secondary_offline_r100(dev):
     counts = [len(m.indexes) for m in sw.gpmodels[0]]
     ok = counts == [int(c) for c in g["counts_final"]] and bool(np.array_equal(sw.resp_assigned[-1].numpy(), g["resp_assigned"][-1]))
     ref = float(g["wall_s"])
-    return {"workload": "BASELINE configs[0]: GPI_HDP.include_batch, MIT-BIH record 100 lead 0 (2272 beats, T=90), settings of "
+    return {"workload": f"BASELINE {cfg}: GPI_HDP.include_batch, MIT-BIH record {rec} lead 0 ({y.shape[0]} beats, T=90), settings of "
                         "hdpgpc/tests/test_offline.py, theta injected",
-            "offline_r100_s": times[1], "first_run_s": times[0], "reference_cpu_s": ref, "reference_cpu_s_survey": 119.5,
-            "speedup_vs_reference": ref / times[1], "speedup_vs_survey": 119.5 / times[1], "final_counts": counts,
+            f"offline_r{rec}_s": times[1], "first_run_s": times[0], "reference_cpu_s_survey": survey_s, "reference_cpu_s_traced_run": ref,
+            "speedup_vs_survey": survey_s / times[1], "final_counts": counts,
             "assignments_identical_to_reference": ok, "higher_is_better": False}
+
+
+def secondary_online_t256(dev):
+    """BASELINE configs[4]: the online path, GPI_HDP.include_sample beat by beat at T = 256 (beats resampled), driven as
+    hdpgpc/tests/test_online.py drives the reference, on the two committed traces of the reference's own runs (24 beats of record
+    102; 16 + 16 beats of records 100 / 102 concatenated).  Reports ms per beat of the second (warm) run, the C-ABI calls per
+    beat counted live, and whether every beat took the reference's decision.  (The rank-1 update kernel the config names is
+    opt-in: it needs annealing off, which no driver sets - see secondary_rank1 and DESIGN.md section 0.)"""
+    gdir = os.path.join(ROOT, "tests", "golden")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from online_trace import run_online
+    from hdpgpc_amd import _ffi
+    out = {"workload": "BASELINE configs[4]: GPI_HDP.include_sample, beats resampled to T=256, settings of hdpgpc/tests/test_online.py, "
+                       "theta injected", "higher_is_better": False}
+    calls = [0]
+
+    class Counting:                          # every call into libhdpgpc_hip.so made by the host layer
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, name):
+            fn = getattr(self._lib, name)
+
+            def wrapped(*a):
+                calls[0] += 1
+                return fn(*a)
+            return wrapped
+
+    for tag, name in (("r102_n24", "include_sample_r102_t256_n24.npz"), ("r100_r102_n32", "include_sample_r100_r102_t256_n32.npz")):
+        g = np.load(os.path.join(gdir, name))
+        run_online(g)                        # warm-up
+        torch.cuda.synchronize()
+        real = _ffi.lib
+        _ffi.lib = Counting(real)
+        calls[0] = 0
+        try:
+            t0 = time.perf_counter()
+            sw, tr = run_online(g)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            _ffi.lib = real
+        n = len(tr)
+        same = all(tr[i][0] == int(g["state"][i]) and tr[i][1] == int(g["M"][i]) and np.array_equal(tr[i][2], g[f"b{i}_labels"])
+                   for i in range(n))
+        out[tag] = {"beats": n, "ms_per_beat": 1e3 * dt / n, "c_abi_calls_per_beat": calls[0] / n, "clusters_at_end": int(sw.M),
+                    "reference_cpu_s": float(g["secs"].sum()), "reference_ms_per_beat": 1e3 * float(g["secs"].sum()) / n,
+                    "decisions_identical_to_reference": bool(same)}
+    out["ms_per_beat"] = out["r102_n24"]["ms_per_beat"]
+    kt = os.path.join(ROOT, "profiles", "r04_online_kernel_stats.json")
+    if os.path.exists(kt):                   # rocprofv3 kernel trace of tools/time_online.py (launch counts cannot be taken live)
+        out["kernel_trace"] = json.load(open(kt))
+    return out
 
 
 def secondary_shared_grid(dev, ops, S=16384, T=90, reps=10):
@@ -281,7 +333,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only (used for the PMC passes)")
-    ap.add_argument("--no-offline", action="store_true", help="skip the record-100 include_batch secondary (kernel-trace runs: it is ~10^5 launches)")
+    ap.add_argument("--no-offline", action="store_true", help="skip the driver-level secondaries (include_batch on records 100 / 102, include_sample at T = 256: ~10^5 launches)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on a one-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--segments", type=int, default=0, help="override the batch size (rehearsals only; 0 = the named config)")
@@ -407,7 +459,9 @@ def main():
                                "(k_trtri), triangular products, column norms for the diagonal prior scale)")
             res["secondary_matrix_terms_T256"] = big
             if not args.no_offline:
-                res["offline_r100"] = secondary_offline_r100(dev)
+                res["offline_r100"] = secondary_offline(dev, "100", 119.5, "configs[0]")
+                res["offline_r102"] = secondary_offline(dev, "102", 348.0, "configs[2]")
+                res["online_t256"] = secondary_online_t256(dev)
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)

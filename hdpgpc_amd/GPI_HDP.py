@@ -121,6 +121,8 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         cond = gp.GPR_dynamic(self.ini_gamma_def, self.ini_sigma_def)
         gp.initial_conditions(ini_A=cond[0], ini_Gamma=cond[1], ini_C=cond[2], ini_Sigma=cond[3])
         gp.theta_source = self
+        # the prior scales are gamma I / sigma I by construction (GPR_dynamic): spare return_LDS_param_likelihood its device test
+        gp._def_diag_key, gp._def_diag = (id(gp.Sigma_def), id(gp.Gamma_def)), True
         return gp
 
     def create_wp_sys_default(self):
@@ -143,6 +145,8 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         g.theta_source = gpmodel.theta_source
         g.rank1_scoring, g._Lobs = gpmodel.rank1_scoring, gpmodel._Lobs
         g.gp.fitted = gpmodel.gp.fitted
+        if getattr(gpmodel, "_def_diag_key", None) == (id(g.Sigma_def), id(g.Gamma_def)):     # same prior objects: same verdict
+            g._def_diag_key, g._def_diag = gpmodel._def_diag_key, gpmodel._def_diag
         return g
 
     def selected_gpmodels(self):

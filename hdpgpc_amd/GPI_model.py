@@ -161,6 +161,7 @@ class GPI_model:
         self.noise_bounds = (1e-10, 1e10)
         self._stk = {}
         self._pending = []
+        self._defer_checks = False
 
     # ------------------------------------------------------------------ state (a12)
     def cond_to_torch(self, x):
@@ -341,6 +342,14 @@ class GPI_model:
         self._pending.append((what, info))
         return ops.gemm_batched(Z[0], Z[0], transA=True)
 
+    def _raise(self, info, what):
+        """raise_on_info now, or - with _defer_checks set (the online step's would-be new cluster: five small evaluations in a row,
+        each of which would wait for the device) - at the caller's next _check_pending()."""
+        if self._defer_checks:
+            self._pending.append((what, info))
+        else:
+            ops.raise_on_info(info, what)
+
     def _check_pending(self):
         """One host sync for all the LAPACK infos collected since the last check; raises like torch.linalg.cholesky."""
         if self._pending:
@@ -400,7 +409,8 @@ class GPI_model:
             f, c, A, Gamma, C, Sigma = self.f_star[-1], self.cov_f[-1], self.A[-1], self.Gamma[-1], self.C[-1], self.Sigma[-1]
         first = bool(torch.equal(c, self.gp.kernel(self.x_basis, self.x_basis)))
         out = self._posterior(f, c, y, A, Gamma / h, C, Sigma / h, first, h=h, x_warped=x)
-        self._check_pending()
+        if not self._defer_checks:
+            self._check_pending()
         return out
 
     def find_closest_lower(self, t):
@@ -1012,7 +1022,7 @@ class GPI_model:
             fnt = torch.full((1, 1), fn, dtype=f64, device=self.device) if first else None
             quad, _, info = plan.loglik(x.reshape(1, -1).contiguous(), y, first_noise=fnt, want_logdet=False)
             quad = quad.reshape(-1)
-        ops.raise_on_info(info, "log_sq_error")
+        self._raise(info, "log_sq_error")
         return -0.5 * quad[0] - 0.5 * y.shape[1] * LOG2PI
 
     # ------------------------------------------------------------------ a6
@@ -1109,14 +1119,14 @@ class GPI_model:
         if only is not None:
             cur, prev, par, cov = [cur[only]], [prev[only]], [par[only]], [cov[only]]
         T = self.x_basis.shape[0]
-        ix = lambda a: torch.as_tensor(a, device=self.device)  # noqa: E731
+        ix = lambda a: ops.to_dev(a, torch.int64, self.device)  # noqa: E731
         Gam = self._S("Gamma")[ix(par)].clone()
         if only is None or only == 0:
             Gam[0] = Gam[0] * h_ini                                  # GPI_model.py:293
         out, info = ops.lat_error(self._S("f_star_sm")[ix(cur)].reshape(-1, T).contiguous(),
                                   self._S("f_star_sm")[ix(prev)].reshape(-1, T).contiguous(), self._S("A")[ix(par)].contiguous(), Gam,
                                   self._S("cov_f_sm")[ix(cov)].contiguous())
-        ops.raise_on_info(info, "log_lat_error")
+        self._raise(info, "log_lat_error")
         return out - 0.5 * T * LOG2PI
 
     def log_lat_error(self, i, h_ini):
@@ -1137,7 +1147,7 @@ class GPI_model:
         col = self._stk.get("_lat_col")
         if col is None or col[0] is not ent[1] or col[1].shape[0] < n:
             buf = torch.zeros(max(64, 2 * n), dtype=f64, device=self.device)
-            buf[torch.as_tensor(self.indexes, device=self.device)] = ent[1]
+            buf[ops.to_dev(self.indexes, torch.int64, self.device)] = ent[1]
             col = self._stk["_lat_col"] = (ent[1], buf)
         return col[1][:n]
 
@@ -1169,7 +1179,7 @@ class GPI_model:
             self._def_diag_key = key
         out, info = ops.mniw_loglik(torch.stack(Ms).contiguous(), torch.stack(Ss).contiguous(), torch.stack(means).contiguous(),
                                     None, torch.stack(scales).contiguous(), scale_is_diagonal=self._def_diag)
-        ops.raise_on_info(info, "return_LDS_param_likelihood")
+        self._raise(info, "return_LDS_param_likelihood")
         return torch.sum(out) / T * 100.0
 
     def lds_param_likelihood_value(self):

@@ -387,7 +387,10 @@ int hgp_lds_chain_gather2_batched_f64(const hgp_chain_gather_desc* descs_dev, in
   if (n_chains == 0) return 0;
   if (!descs_dev || n_chains < 0 || T <= 0) return -1;
   const long total = 8L * T * T + 2L * T;
-  hipLaunchKernelGGL(k_chain_gather2_b, dim3((unsigned)((total + 255) / 256), (unsigned)n_chains), dim3(256), 0, (hipStream_t)stream, descs_dev);
+  // a grid-stride loop per chain: every block pays the two diagonal means (2 T strided loads + a barrier) before it copies, so a
+  // block per 256 elements (2 050 blocks per chain at T = 256) spent more time there than copying: 288 us for 23 chains
+  const long blocks = std::min<long>((total + 255) / 256, n_chains >= 8 ? 64 : 256);
+  hipLaunchKernelGGL(k_chain_gather2_b, dim3((unsigned)blocks, (unsigned)n_chains), dim3(256), 0, (hipStream_t)stream, descs_dev);
   return launch_status();
 }
 

@@ -108,6 +108,7 @@ class OnlinePool:
         self.badc_all = torch.zeros((cap, 2), dtype=torch.int32, device=dev)     # candidate steps (cleared per beat)
         self.sync_all = torch.zeros(cap, dtype=torch.int32, device=dev)
         self.est_mean, self.mean_last = new(cap, T), new(cap, T)
+        self.ini_noise_all = new(cap)
         self.lists = _LevelLists(cap, dev)
         self.descs_dirty = True
         self._base = np.zeros((cap, 8), dtype=np.int64)        # byte addresses of the stacks / step buffers of every slot
@@ -149,6 +150,7 @@ class OnlinePool:
         self._bufp[c] = [ch["bufs"][k].data_ptr() for k in ("f_post", "f_sm_prev", "P_sm_prev")]
         self.descs_dirty = True
         dd = sl.g
+        self.ini_noise_all[c] = 1e-2 * torch.mean(torch.diagonal(dd.Sigma[0]))
         self.MN_mean[2 * c].copy_(dd.C_def), self.MN_mean[2 * c + 1].copy_(dd.A_def)
         self.MN_scale[2 * c].copy_(dd.Sigma_def), self.MN_scale[2 * c + 1].copy_(dd.Gamma_def)
         self.slots.append(sl)
@@ -157,12 +159,13 @@ class OnlinePool:
     def supports(g):
         """The chain step covers: dynamic model, no estimation limit, at least one member, last filtered = last smoothed state
         (always true for a chain grown online), no tracked rank-1 factor."""
-        if g.N < 1 or g.estimation_limit != np.inf or g._rank1_on() or not bool(torch.any(g.Gamma[-1] != 0)):
+        if g.N < 1 or g.estimation_limit != np.inf or g._rank1_on() or not g._is_dynamic():
             return False
         n = len(g.f_star)
         if not (n == len(g.f_star_sm) == len(g.cov_f) == len(g.cov_f_sm) == len(g.A) == len(g.Gamma) == len(g.C) == len(g.Sigma)):
             return False
-        return bool(torch.equal(g.f_star[-1], g.f_star_sm[-1])) and bool(torch.equal(g.cov_f[-1], g.cov_f_sm[-1]))
+        same = lambda a, b: a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape) or bool(torch.equal(a, b))   # noqa: E731
+        return same(g.f_star[-1], g.f_star_sm[-1]) and same(g.cov_f[-1], g.cov_f_sm[-1])
 
     def adopt(self, g):
         """Move the model's per-step lists into a slot's stacks (the model keeps reading them through views)."""
@@ -188,8 +191,11 @@ class OnlinePool:
                                torch.stack((eye if mi.m_r_cov is None else mi.m_r_cov, eye if mo.m_r_cov is None else mo.m_r_cov)),
                                torch.stack((mi.scale, mo.scale)))).contiguous()
         sl.ch = ch
-        sl.ini_noise = 1e-2 * float(torch.mean(torch.diagonal(g.Sigma[0])))                       # log_sq_error's `first` inflation
-        sl.def_diag = all(bool(torch.equal(s_, torch.diag(torch.diagonal(s_)))) for s_ in (g.Sigma_def, g.Gamma_def))
+        sl.ini_noise = None                                   # log_sq_error's `first` inflation: on the device (self.ini_noise_all)
+        if getattr(g, "_def_diag_key", None) == (id(g.Sigma_def), id(g.Gamma_def)):
+            sl.def_diag = g._def_diag
+        else:
+            sl.def_diag = all(bool(torch.equal(s_, torch.diag(torch.diagonal(s_)))) for s_ in (g.Sigma_def, g.Gamma_def))
         sl.bad0 = 0
         self._bind(sl)
         self._rebind_lists(sl, float(mi.n0))
@@ -320,7 +326,7 @@ class OnlinePool:
         self._step(0, M, dry=True, gather=False)               # begin_beat(y) of this beat gathered the state
         # estimate_new: the beat against (C_last f_post, Sigma_last), `first` inflation for one-member clusters
         Y = self.ybuf.expand(M, T).contiguous()
-        add = np.array([sl.ini_noise if sl.N == 1 else 0.0 for sl in self.slots])
+        add = self.ini_noise_all[:M] * ops.to_dev(np.array([1.0 if sl.N == 1 else 0.0 for sl in self.slots]), f64, self.device)
         ar = np.arange(M, dtype=np.int32)
         quad, _, info = ops.score_each(Y, self.est_mean, self.ws_all[0, 3 * tt:], ar, ar, add, strides=(T, self.WS))
         est = -0.5 * quad - 0.5 * T * LOG2PI
@@ -353,7 +359,7 @@ class OnlinePool:
         put(row(iC, N + 1, tt), self.MN_M, 0, tt), put(row(iS, N + 1, tt), self.MN_S, 0, tt)
         put(row(iA, N + 1, tt), self.MN_M, 1, tt), put(row(iG, N + 1, tt), self.MN_S, 1, tt)
         table = np.stack([np.concatenate(src), np.concatenate(dst), np.concatenate(cnt)], axis=1)
-        tdev = torch.from_numpy(table).to(self.device)
+        tdev = ops.to_dev(table, torch.int64, self.device)
         ops.copy_list(tdev, table.shape[0], tt)
         lat, info_l = ops.lat_error(self.LF_cur[:3 * M], self.LF_prev[:3 * M], self.LA[:3 * M], self.LG[:3 * M], self.LC[:3 * M])
         lat = lat - 0.5 * T * LOG2PI
@@ -381,7 +387,8 @@ class OnlinePool:
             if sl.N >= 2:
                 rr.append(idx[sl.N - 1]), cc.append(c), vv.append(3 * c + 1)
         dev = self.device
-        cols[torch.as_tensor(rr, device=dev), torch.as_tensor(cc, device=dev)] = lat[torch.as_tensor(vv, device=dev)]
+        ix = ops.to_dev(np.array([rr, cc, vv]), torch.int64, dev)
+        cols[ix[0], ix[1]] = lat[ix[2]]
         return est, cols, lds
 
     # ------------------------------------------------------------------ commit
@@ -428,7 +435,7 @@ class OnlinePool:
             g._stk["_lat_all"] = (self._lat_key(g), new)
             col = g._stk.get("_lat_col")                       # the scattered column: two entries change
             if col is not None and col[0] is lat_old[1] and col[1].shape[0] > int(index):
-                col[1][torch.as_tensor([g.indexes[0], int(index)], device=self.device)] = out
+                col[1][ops.to_dev([g.indexes[0], int(index)], torch.int64, self.device)] = out
                 g._stk["_lat_col"] = (new, col[1])
         self._pending = (sl, info)
 

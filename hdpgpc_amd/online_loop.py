@@ -50,7 +50,7 @@ class OnlineLoop:
         order = torch.argsort(torch.sum(resp, dim=0), descending=True)
         resp = resp[:, order]
         respPair = respPair[:, order, :][:, :, order]
-        od = order.to(q.device)
+        od = ops.to_dev(order, torch.int64, q.device)
         q, q_lat = q.index_select(1, od), q_lat.index_select(1, od)
         for ld in range(self.n_outputs):
             self.gpmodels[ld] = [self.gpmodels[ld][int(order[i])] for i in range(self.M)]
@@ -102,8 +102,9 @@ class OnlineLoop:
         startPi = torch.as_tensor(_digamma(st[:M]) - _digamma(np.sum(st[:M + 1])), dtype=f64)
         if liks is not None:
             Qw = Qw.clone()
-            Qw[:, -1, :] += torch.as_tensor(np.asarray(liks, dtype=np.float64), device=dev)[None, :]
-        labels, pairs, last = ops.hmm_local_terms(Qw.contiguous(), self.compute_trans_pi(K, startPi).to(dev), self.compute_trans_A(K).to(dev))
+            Qw[:, -1, :] += ops.to_dev(np.asarray(liks, dtype=np.float64), f64, dev)[None, :]
+        labels, pairs, last = ops.hmm_local_terms(Qw.contiguous(), ops.to_dev(self.compute_trans_pi(K, startPi), f64, dev),
+                                                  ops.to_dev(self.compute_trans_A(K), f64, dev))
         flat = torch.cat([labels.reshape(-1).to(f64), pairs.reshape(-1).to(f64), last.reshape(-1)]).cpu().numpy()
         lab = flat[:B * N].astype(np.int64).reshape(B, N)
         prs = flat[B * N:2 * B * N].astype(np.int64).reshape(B, N)
@@ -129,14 +130,19 @@ class OnlineLoop:
         from the hard assignment itself (labels / pair_first of ONE score matrix, host ints), the two device sums over the
         assigned entries and the clusters' MNIW parameter likelihoods lds [n_cols] - no [T, K, K] table is built."""
         lab, prs = labels[:n_rows], pairs[:n_rows]
-        start = np.zeros(n_cols)
-        if lab[0] < n_cols:
-            start[lab[0]] = 1.0
-        i, j = prs // K, prs % K
-        ok = (i < n_cols) & (j < n_cols)
-        trans = np.zeros((n_cols, n_cols))
-        np.add.at(trans, (i[ok], j[ok]), 1.0)
-        elbo_lin = self._elbo_linears_counts(start, trans, n_cols, post=post, one_sample=True) * 1
+        # the HDP terms depend on the hard assignment only: candidates that move a score without moving an assignment share them
+        memo = self.__dict__.setdefault("_lin_memo", {})
+        key = (lab.tobytes(), prs.tobytes(), n_cols, post, id(self.rho), id(self.transTheta))
+        elbo_lin = memo.get(key)
+        if elbo_lin is None:
+            start = np.zeros(n_cols)
+            if lab[0] < n_cols:
+                start[lab[0]] = 1.0
+            i, j = prs // K, prs % K
+            ok = (i < n_cols) & (j < n_cols)
+            trans = np.zeros((n_cols, n_cols))
+            np.add.at(trans, (i[ok], j[ok]), 1.0)
+            elbo_lin = memo[key] = self._elbo_linears_counts(start, trans, n_cols, post=post, one_sample=True) * 1
         sums = [float(v) for v in np.bincount(lab[lab < n_cols], minlength=n_cols)]
         tot = sum(sums)
         elbo_lds = 0.0
@@ -182,6 +188,7 @@ class OnlineLoop:
                                       "minibatch=0); the reference's new_params_weighted path (GPI_HDP.py:2195) is not")
         D, dev, ld = self.n_outputs, self.device, 0
         _tick("outside")
+        self._lin_memo = {}
         t = self.T
         self.T = self.T + 1
         T_all = self.T
@@ -206,7 +213,7 @@ class OnlineLoop:
         info0 = None
         if pool is not None:
             slot_of = [g._slot for g in mods]
-            sl_dev = torch.as_tensor(slot_of, device=dev)
+            sl_dev = ops.to_dev(slot_of, torch.int64, dev)
             sc, info0 = pool.begin_beat(y[:, ld])
             q_aux[-1, :M, ld] = sc[sl_dev]
         elif M > 0:
@@ -227,9 +234,14 @@ class OnlineLoop:
             prov = self.gpmodel_deepcopy(self.gpmodels[ld][m_w])
             prov.reinit_GP(save_last=False)
             prov.reinit_LDS(save_last=False)
+            prov._defer_checks = True                                # its LAPACK statuses are read together, below
             q_prev[-1, -1, ld] = prov.estimate_new_and_include(t, x, y[:, [ld]]) + liks[-1]
             q_lat_prev[:, -1, ld] = prov.compute_q_lat_all(n_hist, h_ini=1.0)
-            birth_best = int(torch.argmax(q_prev[-1])) == M          # the new cluster scores the beat best: is it worth it?
+            host = torch.stack([torch.argmax(q_prev[-1]).to(f64), prov.return_LDS_param_likelihood()]).cpu()   # one round trip
+            prov._defer_checks = False
+            prov._check_pending()
+            birth_best = int(host[0]) == M                           # the new cluster scores the beat best: is it worth it?
+            lds_prov = float(host[1])
             _tick("prov")
             order = q_ord.tolist() if birth_best else []
             # score tables of every evaluation of this beat: [0] current clusters, [1] with the new cluster, [2 + r] the r best
@@ -241,18 +253,18 @@ class OnlineLoop:
             if order:
                 if pool is not None:
                     m_of = np.argsort(slot_of)                         # cluster index of every slot
-                    est, cols, lds_s = pool.candidates(t, q_lat[:, torch.as_tensor(m_of, device=dev), ld].contiguous(),
+                    est, cols, lds_s = pool.candidates(t, q_lat[:, ops.to_dev(m_of, torch.int64, dev), ld].contiguous(),
                                                        [mods[m].indexes for m in m_of])
                     est, cols, lds_cand = est[sl_dev], cols[:, sl_dev], [float(lds_s[c]) for c in slot_of]
                 else:
                     est, cols, lds_cand = self._eager_candidates(ld, t, x, y, q_lat, n_hist)
                 _tick("candidates")
                 R = len(order)
-                od = torch.as_tensor(order, device=dev)
+                od = ops.to_dev(order, torch.int64, dev)
                 tried = torch.zeros((R, K), dtype=torch.bool, device=dev)             # tried[r, m]: cluster m is among the r + 1 best
                 tried[:, od] = torch.tril(torch.ones((R, R), dtype=torch.bool, device=dev))
                 new_last = Qb[-1].clone()
-                new_last[:M] = est + torch.as_tensor(liks[:M], device=dev)
+                new_last[:M] = est + ops.to_dev(liks[:M], f64, dev)
                 Qc = Qb.unsqueeze(0).repeat(R, 1, 1)
                 Qc[:, -1, :] = torch.where(tried, new_last[None, :], Qb[-1][None, :])
                 cols_full = Lb.clone()
@@ -276,7 +288,7 @@ class OnlineLoop:
             sums = sums.cpu().numpy().reshape(B, 2)
             q_all, elbo = self._bound_from_labels(lab[0], prs[0], K, T_all - 1, M, sums[0, 0], sums[0, 1], lds_cur, post=False)
             q_prev_post, elbo_prev_post = self._bound_from_labels(lab[1], prs[1], K, T_all, M + 1, sums[1, 0], sums[1, 1],
-                                                                  lds_cur + [prov.lds_param_likelihood_value()], post=True)
+                                                                  lds_cur + [lds_prov], post=True)
             elbo_prev_post -= elbo
             q_prev_post -= q_all
             chosen = 0                                                  # index into Qs of the table that is kept

@@ -26,6 +26,51 @@ def _stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
+class _PinnedRing:
+    """Small host arrays (index lists, descriptor tables, K x K transition logs) go to the device through a ring of pinned
+    staging buffers with asynchronous copies: torch.as_tensor(array, device=...) is a BLOCKING copy that first waits for
+    everything queued on the stream - the online step made ~40 of them per beat, each one a hidden synchronisation."""
+    SLOTS, NBYTES = 64, 1 << 16
+
+    def __init__(self):
+        self.bufs = [torch.empty(self.NBYTES, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        self.views = [b.numpy() for b in self.bufs]
+        self.events = [None] * self.SLOTS
+        self.i = 0
+
+
+_ring = None
+_NP_OF = {torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8, torch.bool: np.bool_}
+
+
+def to_dev(a, dtype, device):
+    """A host array / list / CPU tensor as a device tensor of `dtype` without a stream synchronisation."""
+    global _ring
+    if torch.is_tensor(a):
+        if a.is_cuda:
+            return a.to(dtype=dtype).contiguous()
+        a = a.numpy()
+    arr = np.ascontiguousarray(a, dtype=_NP_OF[dtype])
+    dev = torch.device(device)
+    if dev.type != "cuda" or arr.nbytes == 0 or arr.nbytes > _PinnedRing.NBYTES:
+        return torch.as_tensor(arr, dtype=dtype, device=device)
+    if _ring is None:
+        _ring = _PinnedRing()
+    r = _ring
+    i = r.i
+    r.i = (i + 1) % r.SLOTS
+    if r.events[i] is not None:
+        r.events[i].synchronize()          # the copy that last used this slot (64 uploads ago) has long finished
+    nb = arr.nbytes
+    r.views[i][:nb] = arr.reshape(-1).view(np.uint8)
+    out = torch.empty(arr.shape, dtype=dtype, device=device)
+    out.view(-1).view(torch.uint8).copy_(r.bufs[i][:nb], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    r.events[i] = ev
+    return out
+
+
 def _dev64(t, name):
     if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
         raise TypeError(f"{name} must be a contiguous fp64 tensor on the GPU")
@@ -137,7 +182,7 @@ def score_groups(Y, mean, Sigma, item_mat, item_add, item_off, item_cnt, seg_ids
     mstride, sstride = (T, T * T) if strides is None else (int(strides[0]), int(strides[1]))
 
     def up(a, dt):
-        return a.to(device=dev, dtype=dt).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+        return to_dev(a, dt, dev)
 
     im, ia = up(item_mat, torch.int32), (None if item_add is None else up(item_add, torch.float64))
     io, ic = up(item_off, torch.int32), up(item_cnt, torch.int32)
@@ -168,7 +213,7 @@ def score_each(Y, mean, Sigma, seg_mat, seg_mean=None, seg_add=None, jitter_rel=
     def up(a, dt):
         if a is None:
             return None
-        return a.to(device=dev, dtype=dt).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+        return to_dev(a, dt, dev)
 
     sm, sme, sa = up(seg_mat, torch.int32), up(seg_mean, torch.int32), up(seg_add, torch.float64)
     if T > 128:   # cooperative kernels: one work item (one workgroup) per segment

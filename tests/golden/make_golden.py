@@ -736,7 +736,11 @@ def gen_include_sample(tag, rec, n, T_res=None, lead=0, with_warp=False):
     off, theta injected) on the first n beats of a record - optionally resampled to T_res points by linear interpolation
     (BASELINE configs[4] names T = 256) - and record after every beat what the step decided and scored."""
     import time
-    raw = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:, :, [lead]]
+    if isinstance(rec, (list, tuple)):     # BASELINE configs[4] "concatenated MIT-BIH records": n beats of each record, one after the other
+        raw = np.concatenate([np.load(os.path.join(REF, "data", "mitbih", f"{r}.npy"))[:n, :, [lead]] for r in rec])
+        n = raw.shape[0]
+    else:
+        raw = np.load(os.path.join(REF, "data", "mitbih", f"{rec}.npy"))[:, :, [lead]]
     if T_res is not None:
         tt = np.linspace(0, raw.shape[1] - 1, T_res)
         raw = np.stack([np.interp(tt, np.arange(raw.shape[1]), r[:, 0]) for r in raw[:max(n, 32)]])[:, :, None]
@@ -873,6 +877,8 @@ if __name__ == "__main__":
         gen_include_sample("r102_n25_warp", "102", 25, with_warp=True)
     if "online256" in which and "trace" in which:
         gen_include_sample("r102_t256_n24", "102", 24, T_res=256)
+    if "online256x2" in which:         # configs[4]: two records concatenated (16 beats of record 100, then 16 of record 102), T = 256
+        gen_include_sample("r100_r102_t256_n32", ["100", "102"], 16, T_res=256)
     if "reload" in which:
         gen_reload("r102", "102")
     if "reload2" in which:

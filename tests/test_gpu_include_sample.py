@@ -36,6 +36,21 @@ def test_include_sample_r102_t256():
     print(f"include_sample, 24 beats T=256: {wall:.2f} s (reference {float(g['secs'].sum()):.1f} s), worst {worst:.2e}")
 
 
+def test_include_sample_two_records_t256():
+    """configs[4] as worded: CONCATENATED records - 16 beats of record 100 followed by 16 of record 102, resampled to T = 256
+    (make_golden.py online256x2).  Unlike the record-102 fixture, whose every beat opens a cluster, this one also walks the
+    committed-member path of the persistent chains (two beats join an existing cluster; 30 clusters at the end)."""
+    g = golden("include_sample_r100_r102_t256_n32.npz")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    _, tr = run_online(g)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    worst = compare_online(g, tr, 1e-8)
+    assert sum(1 for i in range(1, 32) if int(g["M"][i]) == int(g["M"][i - 1])) >= 2       # beats that join an existing cluster
+    print(f"include_sample, 16 + 16 beats of records 100 / 102 at T=256: {wall:.2f} s (reference {float(g['secs'].sum()):.1f} s), worst {worst:.2e}")
+
+
 def test_online_rank1_factor_tracking_t256():
     """BASELINE configs[4] names the rank-1 Cholesky update kernel as part of the online path at T = 256.  Its consumer: with
     annealing off Sigma_i is an exact multiple of the observation MNIW's scale, whose factor then follows the recursion
