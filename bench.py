@@ -416,12 +416,15 @@ def main():
         kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)]))
         flops = (hi - lo) * k_cl * algorithmic_flops_per_eval(t_len)          # per launch on this rank
         achieved = flops / (kern_ms * 1e-3) / 1e12
-        traffic = mfma_per_pair = None
+        traffic = mfma_per_pair = traffic_src = None
         tf = os.path.join(ROOT, "profiles", "pairs_traffic.json")
         if world == 1 and os.path.exists(tf):
             tfj = json.load(open(tf))
             traffic = tfj.get("hbm_bytes_per_launch")
             mfma_per_pair = tfj.get("mfma_f64_instructions_per_pair")
+            traffic_src = {"file": "profiles/pairs_traffic.json", "measured_commit": tfj.get("measured_commit"),
+                           "measured_date": tfj.get("measured_date"),
+                           "note": "PMC counters of a separate rocprofv3 --pmc run of this bench (tools/profile_bench.sh), not of this run"}
         res = {
             "metric": "GP log-lik evals/sec (NxK batch, T-point segments)",
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -437,6 +440,8 @@ def main():
                          "kernel": kern, "kernel_ms": kern_ms, "pairs_per_launch": (hi - lo) * k_cl,
                          "algorithmic_flops_per_eval": algorithmic_flops_per_eval(t_len)},
         }
+        if traffic_src:
+            res["roofline"]["traffic_source"] = traffic_src
         if mfma_per_pair:   # what the kernel EXECUTES (PMC count): cov_f = K** + E^T M' E is formed per pair before the one
             # Cholesky the yardstick counts, so `frac` cannot exceed algorithmic / executed even at 100 % MFMA-busy
             ex = mfma_per_pair * 2048.0

@@ -1,8 +1,11 @@
 """Drop-in surface of hdpgpc/hdpgpc/GPI_HDP.py for the GP-emission hot path (Face 1).
 
-Built: the constructor (same keyword arguments, GPI_HDP.py:100-111), the per-(lead, cluster) model table ``gpmodels``,
-and the two methods that are pure hot-path wrappers -
+Built: the constructor (same keyword arguments, GPI_HDP.py:100-111), the per-(lead, cluster) model table ``gpmodels`` and the
+driver entry points -
 
+* ``include_batch`` (GPI_HDP.py:805-943, ``warp=`` / the drivers' ``with_warp=``; offline_loop.py) and
+  ``cluster_new_batch(learning=True)`` (GPI_HDP.py:3005-3145): the offline variational loop;
+* ``include_sample`` (GPI_HDP.py:1906-2208; online_loop.py + online_chain.py): the online step, one lead, ``with_warp=False``;
 * ``reload_model_from_labels`` (GPI_HDP.py:3952-4035): one ``GPI_model.full_pass_weighted`` per (lead, class) from given
   labels, then the HDP pseudo-counts (host-side, hdp_global.py);
 * ``cluster_new_batch(learning=False)`` (GPI_HDP.py:2975-3003): the N x M batch of frozen-model scores
@@ -11,9 +14,9 @@ and the two methods that are pure hot-path wrappers -
   arg-max, all on the device (ops.hmm_messages, ops.assign);
 
 plus the small public helpers they and the drivers use (``LogLik``, ``_safe_exp``, ``weight_mean``, ``forward``,
-``backward``, ``coupled_state_coef``, ``compute_trans_A/pi``, ``selected_gpmodels``).  NOT built: the variational control
-loop (``include_batch`` / ``include_sample`` birth-merge proposals, ELBO bookkeeping, warping) - out of scope of this
-build; those methods raise NotImplementedError.
+``backward``, ``coupled_state_coef``, ``compute_trans_A/pi``, ``selected_gpmodels``).  NOT built (each raises
+NotImplementedError): ``include_sample(with_warp=True)`` (the reference's own path raises at its second beat), ``classify=True``,
+several leads online, static models, ``estimation_limit``, inducing points, ``kernels=`` objects, ``bayesian_params=False``.
 
 Kernel hyper-parameters: the reference fits them with gpytorch on the first member of every cluster (GPI.py:610-770).
 ``GPI_HDP.fixed_theta = (outputscale, lengthscale, noise)`` injects them instead (what the golden fixtures do); with

@@ -15,6 +15,7 @@ model, shared grid, h = 1 (what hdpgpc/tests run with warp=False).  The gpytorch
 ``fit_kernel_params`` takes theta from ``GPI_model.fixed_theta`` (parity-unpinned piece).
 """
 import math
+from collections.abc import MutableSequence
 
 import numpy as np
 import torch
@@ -26,12 +27,14 @@ f64 = torch.float64
 LOG2PI = math.log(2.0 * math.pi)   # GPI_model.py:89-90
 
 
-class StackList:
+class StackList(MutableSequence):
     """One per-step list of a model (f_star[i], Sigma[i], ... one entry per LDS step in the reference, a12) held as ONE stacked
     device tensor [L, ...].  Reads behave like the reference's Python list of tensors (len, [i], [-1], slices, iteration,
     ``+``); the first mutation (item assignment, append) turns it into a real list (copy-on-write), so a model and its
     copies can share one.  A 2 272-step chain is 8 such lists: building 18 000 tensor objects per pass, and re-stacking
-    them for every batched kernel, was 10 % of the offline loop's wall-clock."""
+    them for every batched kernel, was 10 % of the offline loop's wall-clock.  It is a collections.abc.MutableSequence (pop,
+    extend, insert, del, reversed, ``in`` come with it); torch.stack / torch.cat only take real lists and tuples: pass
+    ``list(m.f_star)`` or use ``m.f_star.stack()``."""
     __slots__ = ("_st", "_ls")
 
     def __init__(self, stack):
@@ -58,8 +61,17 @@ class StackList:
     def __setitem__(self, i, v):
         self._list()[i] = v
 
+    def __delitem__(self, i):
+        del self._list()[i]
+
+    def insert(self, i, v):
+        self._list().insert(i, v)
+
     def append(self, v):
         self._list().append(v)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
 
     def __iter__(self):
         return iter(self._st.unbind(0) if self._ls is None else self._ls)

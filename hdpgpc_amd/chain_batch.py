@@ -58,16 +58,19 @@ def run(jobs):
     full_pass_weighted returns them)."""
     for j in jobs:
         j.x, j.y = j.gp.cond_to_torch(j.x), j.gp.cond_to_torch(j.y)
-    fast = [j for j in jobs if len(j.active) and _graphable(j)]
-    if len(fast) < 2:                                  # nothing to run side by side
-        fast = []
+    by_T = {}                                          # chains advance in lock-step only with chains of their own basis length
+    for j in jobs:
+        if len(j.active) and _graphable(j):
+            by_T.setdefault(int(j.gp.x_basis.shape[0]), []).append(j)
+    groups = [g for g in by_T.values() if len(g) >= 2]  # a lone chain has nothing to run beside
+    fast = [j for g in groups for j in g]
     for j in jobs:
         if not len(j.active):
             j.out = j.prev
-        elif j not in fast:
+        elif not any(j is f for f in fast):
             j.out = j.gp.full_pass_weighted(j.x, j.y, j.resp, q=j.prev[0], q_lat=j.prev[1])
-    if fast:
-        _run_fast(fast)
+    for g in groups:
+        _run_fast(g)
     return [j.out for j in jobs]
 
 

@@ -1719,7 +1719,7 @@ static int tp_for(int n) {   // padded size: wave kernels {32,64,96,128}, cooper
 }
 // Diagnostic switch: HGP_PAIRS_COOP=1 (read when a plan is created) runs the cooperative kernels for T <= 128 too.
 static int tp_plan(int n) {
-  if (n <= HGP_MAX_T_WAVE && env_on("HGP_PAIRS_COOP")) return 64 * ((n + 63) / 64);
+  if (n <= HGP_MAX_T_WAVE && env_on("HGP_PAIRS_COOP")) return 128;   // (k_pairs_cooph<8>; a <4> instance spilled 316 VGPRs and had no use)
   return tp_for(n);
 }
 

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
   int n = blockIdx.x, total = 0;
   if constexpr (!BAND) {
     if (a.fb) {   // the list is complete (previous kernel on the stream); workgroups beyond it have nothing to do
-      total = a.fb[0];
+      total = min(a.fb[0], PAIRS_FB_CAP);
       if (n >= total) return;
       n = a.fb[1 + n];
     }
@@ -364,7 +364,10 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
   const bool band = (NB >= 6) && kcache && !(a.flags & 1) && __builtin_amdgcn_readfirstlane(bbad) == 0;
   if constexpr (BAND) {
     if (!band) {   // not the static pattern: this segment goes to the generic kernel
-      if (tid == 0) a.fb[1 + atomicAdd(&a.fb[0], 1)] = n;
+      if (tid == 0) {   // (the count is clamped on both sides: counters left over from a launch that died must not index past the list)
+        const int slot = atomicAdd(&a.fb[0], 1);
+        if (slot < PAIRS_FB_CAP) a.fb[1 + slot] = n;
+      }
       return;
     }
   }
@@ -1123,9 +1126,16 @@ int launch_pairs(const PairsArgs& a0, hipStream_t st) {
     if (a.out_logdet) a.out_logdet += oo;
     if (a.out_info) a.out_info += oo;
     hipLaunchKernelGGL((k_pairs<NB, true>), dim3(a.N), dim3(64 * WAVES), lds, st, a);
+    const int rc1 = launch_status();
     hipLaunchKernelGGL((k_pairs<NB, false>), dim3(a.N), dim3(64 * WAVES), lds, st, a);
+    const int rc2 = launch_status();
+    if (rc1 || rc2) {   // the generic kernel hands the list back empty; if either launch failed, do it here
+      (void)hipMemsetAsync(a.fb, 0, sizeof(int32_t), st);
+      (void)hipMemsetAsync(a.fb + 1 + PAIRS_FB_CAP, 0, sizeof(int32_t), st);
+      return rc1 ? rc1 : rc2;
+    }
   }
-  return launch_status();
+  return 0;
 }
 
 }  // namespace
@@ -1134,7 +1144,6 @@ int launch_pairs(const PairsArgs& a0, hipStream_t st) {
 int hgp_internal_pairs_fast(const PairsArgs& a, int NB, bool coop, hipStream_t st) {
   if (coop) {   // NB/2 waves per pair (CoopH)
     switch (NB) {
-      case 4: return launch_pairs_cooph<4>(a, st);
       case 8: return launch_pairs_cooph<8>(a, st);
       case 12: return launch_pairs_cooph<12>(a, st);
       default: return launch_pairs_cooph<16>(a, st);

@@ -15,9 +15,10 @@ and N x M x M tables of zeros and ones) and the O(M) HDP terms (hdp_global.py).
 
 The reference's loop is written as three long methods that repeat the same blocks (assign -> rebuild changed clusters -> ELBO
 -> iterate); here those blocks are helpers (``_assign``, ``_rebuild``, ``_elbo_of``, ``_pick_representatives``).  Quirks of
-the reference that change results are kept and marked ``# quirk``.  Warping inside the loop (``warp=True``) is not built:
-with ``warp=False`` the reference's 4-D ``y_trains_w`` is a broadcast view of ``y_trains`` and its ``liks`` are zeros
-(GPI_HDP.py:3441-3446), so neither is materialised here.
+the reference that change results are kept and marked ``# quirk``.  With ``warp=False`` the reference's 4-D ``y_trains_w`` is a
+broadcast view of ``y_trains`` and its ``liks`` are zeros (GPI_HDP.py:3441-3446), so neither is materialised; ``warp=True`` warps every
+segment onto every cluster's representative (``warp_batch_by_resp_amtgp_cached``, GPI_HDP.py:3412-3525: hgp_warp_batch_f64 + the a11
+prior score) and carries the 4-D tensor through the same helpers.
 """
 import numpy as np
 import torch

@@ -250,12 +250,14 @@ class PairsPlan:
                                                   theta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                                   _ptr(self._buf), nbytes), "pairs_plan_create")
         self.info = torch.zeros(self.K, dtype=torch.int32, device=device)
+        self._routed = False
         self.set_accuracy(acc_tol)
 
     def set_accuracy(self, tol):
         """Threshold on accuracy_bound() above which a cluster takes the solve-based kernel (next update())."""
         self.acc_tol = float(tol)
         _ffi.check(_ffi.lib.hgp_pairs_plan_set_accuracy(self._h, self.acc_tol), "pairs_plan_set_accuracy")
+        self._routed = False           # the per-cluster routing flags belong to the previous threshold until update() runs
         return self
 
     def update(self, x_basis, mean, Sigma):
@@ -266,6 +268,7 @@ class PairsPlan:
         self._keep = (x_basis, mean, Sigma)
         _ffi.check(_ffi.lib.hgp_pairs_plan_update(self._h, _ptr(x_basis), _ptr(mean), _ptr(Sigma), _ptr(self.info),
                                                   _stream()), "pairs_plan_update")
+        self._routed = True
         return self
 
     def scalars(self):
@@ -292,18 +295,33 @@ class PairsPlan:
         score=True: the first output is the reference's score -0.5 quad - 0.5 Ts log(2 pi) (GPI_model.py:285), written by the
         kernels themselves (hgp_pairs_plan_set_score_output) - no arithmetic launch behind the pair kernels.
         Every output element is written by exactly one pair kernel: the buffers are not cleared first."""
+        if not self._routed:
+            raise RuntimeError("PairsPlan: update() must run after set_accuracy() / before the first loglik() - the kernels skip "
+                               "clusters by the routing flags update() writes, and the outputs are not cleared")
         x = _dev64(x, "x")
         y = _dev64(y, "y")
         N, Ts = x.shape
         dev = x.device
         shape = (N,) if sel is not None else (N, self.K)
-        if sel is not None:
-            sel = torch.as_tensor(sel, device=dev).to(torch.int32).contiguous()
         if first_noise is not None:
             first_noise = _dev64(first_noise.reshape(shape), "first_noise")
-        quad = torch.empty(shape, dtype=torch.float64, device=dev)
+        if sel is not None:
+            # a selection outside [0, K) would leave its output element unwritten: host arrays are checked here, device arrays
+            # get outputs that start as NaN / info = 1 (two fill launches on the per-segment path only)
+            if not torch.is_tensor(sel) or not sel.is_cuda:
+                sel_h = np.asarray(sel)
+                if sel_h.size and (sel_h.min() < 0 or sel_h.max() >= self.K):
+                    raise ValueError(f"PairsPlan.loglik: sel must lie in [0, {self.K})")
+                quad = torch.empty(shape, dtype=torch.float64, device=dev)
+                info = torch.empty(shape, dtype=torch.int32, device=dev) if want_info else None
+            else:
+                quad = torch.full(shape, float("nan"), dtype=torch.float64, device=dev)
+                info = torch.ones(shape, dtype=torch.int32, device=dev) if want_info else None
+            sel = to_dev(sel, torch.int32, dev)
+        else:
+            quad = torch.empty(shape, dtype=torch.float64, device=dev)
+            info = torch.empty(shape, dtype=torch.int32, device=dev) if want_info else None
         logdet = torch.empty(shape, dtype=torch.float64, device=dev) if want_logdet else None
-        info = torch.empty(shape, dtype=torch.int32, device=dev) if want_info else None
         if bool(score) != self._score_out:
             _ffi.check(_ffi.lib.hgp_pairs_plan_set_score_output(self._h, int(bool(score))), "pairs_plan_set_score_output")
             self._score_out = bool(score)
@@ -548,7 +566,7 @@ class GemmList:
         host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
         self._dev = host.to(self.device)
         self._map = None
-        if len(self._items) > 8:            # long lists: per-tile map instead of the per-wave walk over the items
+        if 8 < len(self._items) <= 65535:   # long lists: per-tile map instead of the per-wave walk (16-bit item index; longer lists walk)
             m = np.concatenate([(i << 16) | np.arange(n, dtype=np.uint32) for i, n in enumerate(self._item_tiles)]).astype(np.uint32)
             self._map = torch.from_numpy(m.view(np.int32)).to(self.device)
             self._cum = np.concatenate([[0], np.cumsum(self._item_tiles)])

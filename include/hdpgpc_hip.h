@@ -138,7 +138,8 @@ int hgp_pairs_plan_set_score_output(hgp_pairs_plan* plan, int on);
 /* sel[N] (may be NULL): segment n is scored against cluster sel[n] only - the per-segment LDS step of
  * GPI_model.compute_sq_err_all's irregular-grid loop (GPI_model.py:535-545); outputs and first_noise are then [N].
  * A plan serves one stream at a time (its workspace and, for Ts > 128, the overflow areas handed out inside the kernel belong to
- * the call; the hand-out flags are reset at the start of every call). */
+ * the call; the hand-out flags are reset at the start of every call).  The fall-back list of segments whose E is not
+ * block-tridiagonal and its two counters are plan-owned scratch as well: two calls on one plan must be ordered on one stream. */
 int hgp_loglik_pairs_f64(const hgp_pairs_plan* plan, const double* x, const double* y, int N, int Ts,
                          const double* first_noise, const int32_t* sel, double* out_quad, double* out_logdet,
                          int32_t* out_info, void* stream);

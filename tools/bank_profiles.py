@@ -1,11 +1,13 @@
-"""Copy the summaries of a tools/profile_bench.sh run (gpurun_out/prof_TAG) into profiles/r03_* and refresh pairs_traffic.json."""
-import json, shutil, sys
+"""Copy the summaries of a tools/profile_bench.sh run (gpurun_out/prof_TAG) into profiles/<round>_* and refresh pairs_traffic.json:
+    python tools/bank_profiles.py TAG [ROUND=r04]"""
+import datetime, json, shutil, subprocess, sys
 tag = sys.argv[1]
+RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
 P = f"gpurun_out/prof_{tag}"
-shutil.copy(P + "/bench.json", "profiles/r03_bench.json")
-shutil.copy(P + "/kernel_stats.csv", "profiles/r03_kernel_stats.csv")
-shutil.copy(P + "/offline_kernel_stats.csv", "profiles/r03_offline600_kernel_stats.csv")
-shutil.copy(P + "/summary.json", "profiles/r03_pmc_summary.json")
+shutil.copy(P + "/bench.json", f"profiles/{RND}_bench.json")
+shutil.copy(P + "/kernel_stats.csv", f"profiles/{RND}_kernel_stats.csv")
+shutil.copy(P + "/offline_kernel_stats.csv", f"profiles/{RND}_offline600_kernel_stats.csv")
+shutil.copy(P + "/summary.json", f"profiles/{RND}_pmc_summary.json")
 s = json.load(open(P + "/summary.json"))
 p = s["pmc_mean_per_dispatch"]["k_pairs<8, true>"]
 t = json.load(open("profiles/pairs_traffic.json"))
@@ -14,7 +16,10 @@ t["WRITE_SIZE_KB"] = p["WRITE_SIZE"]
 t["hbm_bytes_per_launch"] = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
 t["sq"] = {k: v for k, v in p.items() if k.startswith("SQ_")}
 t["mfma_f64_instructions_per_pair"] = round(p["SQ_INSTS_VALU_MFMA_F64"] / 16384)
-t["source"] = f"profiles/r03_pmc_summary.json (tools/profile_bench.sh {tag}: one rocprofv3 --pmc pass per counter group)"
+t["source"] = f"profiles/{RND}_pmc_summary.json (tools/profile_bench.sh {tag}: one rocprofv3 --pmc pass per counter group)"
+# bench.py copies these two into its JSON line: the counters are NOT measured in the driver's run, the line says which code they belong to
+t["measured_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() + " (+ working tree)"
+t["measured_date"] = datetime.date.today().isoformat()
 json.dump(t, open("profiles/pairs_traffic.json", "w"), indent=1)
 b = json.load(open(P + "/bench.json"))
 n = 16384
