@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC   = hdpgpc_amd/csrc
-SRCS   = $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
+SRCS   = $(CSRC)/hgp_kernels.hip $(CSRC)/hgp_pairs.hip $(CSRC)/hgp_pairs_acc.hip $(CSRC)/hgp_matlik.hip $(CSRC)/hgp_matlik_coop.hip $(CSRC)/hgp_assign.hip $(CSRC)/hgp_warp.hip $(CSRC)/hgp_chain.hip
 HDR    = $(CSRC)/tile_f64.hpp $(CSRC)/hgp_internal.hpp include/hdpgpc_hip.h
 OBJDIR = build/obj
 OBJS   = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))

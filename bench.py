@@ -246,6 +246,47 @@ def secondary_pairs_t90(dev, ops, synth, N=2048, K=8, T=90, reps=10):
                          "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T)}}
 
 
+def secondary_pairs_generic(dev, ops, synth, N=2048, K=8, T=128, reps=10):
+    """The mask-driven pair kernel k_pairs<8, false> - what scores every segment whose E is not the block-tridiagonal pattern of
+    the static sweeps (other length-scales, other spacings).  (a) the headline batch with the static schedule switched off
+    (HGP_PAIRS_GENERIC=1: identical pairs, identical MFMA count, kernel against kernel); (b) a batch whose segment grids are
+    jittered by +-0.45 points instead of +-0.3 (neighbours stay >= 0.1 apart): entries 13 points off the diagonal come alive, k-steps
+    outside the static schedule, and the band kernel hands those segments over by itself.  Same accounting as the headline (T^3/3 + 3 T^2 FLOPs per eval against the fp64 MFMA peak)."""
+    b = synth.synthetic_batch(N, K, T, seed=20260703)
+    d = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)  # noqa: E731
+    plan = ops.PairsPlan(T, T, b["theta"], device=dev)
+    xb, mean, Sig, y = d(b["xb"]), d(b["mean"]), d(b["Sigma"]), d(b["y"])
+    plan.update(xb, mean, Sig)
+    rng = np.random.default_rng(7)
+    xs = {"band": d(b["x"]), "forced": d(b["x"]), "wide_jitter": d(b["xb"][None, :] + rng.uniform(-0.45, 0.45, size=(N, T)))}
+    out = {}
+    for tag, x in xs.items():
+        if tag == "forced":
+            os.environ["HGP_PAIRS_GENERIC"] = "1"
+        try:
+            for _ in range(2):
+                plan.loglik(x, y, want_logdet=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                quad, _, info = plan.loglik(x, y, want_logdet=False)
+            e1.record()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("HGP_PAIRS_GENERIC", None)
+        assert int(info.abs().max()) == 0 and bool(torch.isfinite(quad).all())
+        ms = e0.elapsed_time(e1) / reps
+        tf = N * K * algorithmic_flops_per_eval(T) / (ms * 1e-3) / 1e12
+        out[tag] = {"kernel_ms": ms, "value": N * K / (ms * 1e-3), "achieved": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS}
+    return {"workload": f"{N} segments x {K} clusters, T={T}: k_pairs<8, true> (band) vs k_pairs<8, false> on the same pairs (forced) and on "
+                        "segment grids jittered by +-0.45 points (wide_jitter: live k-steps outside the static schedule)",
+            "value": out["forced"]["value"], "unit": "evals/s", "kernel_ms": out["forced"]["kernel_ms"],
+            "generic_over_band_same_pairs": out["band"]["kernel_ms"] / out["forced"]["kernel_ms"],
+            "runs": out,
+            "roofline": {"bound": "mfma", "achieved": out["forced"]["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": out["forced"]["frac"], "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T)}}
+
+
 def secondary_rank1(dev, ops, b=1024, T=256, reps=5):
     """BASELINE configs[4]'s kernel: L <- chol(alpha L L^T + beta v v^T) by a rank-1 update, batch of b factors, T = 256.
     HBM-bound: 8 T^2 algorithmic bytes per update (the lower triangle in and out)."""
@@ -451,6 +492,7 @@ def main():
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_shared_grid(dev, ops)
             res["secondary_pairs_T90"] = secondary_pairs_t90(dev, ops, synth)
+            res["secondary_pairs_generic"] = secondary_pairs_generic(dev, ops, synth)
             res["secondary_large_T"] = secondary_large_T(dev, ops, synth)
             # the WHOLE batch of configs[3] on this one GPU: the N = 1 point of the strong-scaling curve `--gpus N > 1` measures
             # (there the headline line itself is configs[3], 32 768 / N rows per rank)

@@ -84,6 +84,11 @@ int hgp_internal_lat_error_wave(const double* f_cur, const double* f_prev, const
 int hgp_internal_mniw_wave(const double* M, const double* Sigma, const double* m_mean, const double* m_r_cov, const double* scale,
                            int scale_is_diagonal, long prior_stride, int T, int b, double* out, int32_t* info, hipStream_t st);
 
+// hgp_matlik_coop.hip: the same two terms for 128 < T <= HGP_MAX_T_COOP, one workgroup per item (factor once, packed factor in ws)
+size_t hgp_internal_matlik_coop_ws_doubles(int T);
+int hgp_internal_mniw_coop(const double* M, const double* Sigma, const double* m_mean, const double* scale, long prior_stride, int T, int b,
+                           double* out, int32_t* info, double* ws, hipStream_t st);
+
 // arguments of the explicit-operator pair kernels (hgp_pairs.hip)
 struct PairsArgs {
   const double* x;

@@ -2048,8 +2048,12 @@ int hgp_mniw_loglik_f64(const double* M, const double* Sigma, const double* m_me
   if (T > HGP_MAX_T_COOP) return -2;
   if (T <= HGP_MAX_T_WAVE)   // fused: one wavefront per item, nothing goes through the workspace
     return hgp_internal_mniw_wave(M, Sigma, m_mean, m_r_cov, scale, scale_is_diagonal, prior_stride, T, b, out, info, (hipStream_t)stream);
-  if (!ws || ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;   // 128 < T <= 256: composition of the batched kernels
+  if (!ws || ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;
   hipStream_t st = (hipStream_t)stream;
+  // the hot path's call (identity right covariance, diagonal prior scale): one fused cooperative kernel per item (hgp_matlik_coop.hip)
+  if (!m_r_cov && scale_is_diagonal && !env_on("HGP_MATLIK_COMPOSE"))
+    return hgp_internal_mniw_coop(M, Sigma, m_mean, scale, prior_stride, T, b, out, info, (double*)ws, st);
+  // everything else at 128 < T <= 256: composition of the batched kernels
   const long tt = (long)T * T;
   double* Sc = (double*)ws;
   double* Z = Sc + (size_t)b * tt;

@@ -1,0 +1,226 @@
+// a9 (matrix_normal_inv_wishart.log_likelihood_MNIW, GPI_model.py:1346-1362) and a8 (GPI_model.log_lat_error,
+// GPI_model.py:288-323) for 128 < T <= 256 as ONE launch each: one workgroup of four waves per item.
+//
+// Until round 4 these sizes ran as compositions of the batched kernels (cooperative Cholesky, L^-1 by block columns, one or two
+// T^3 products, element-wise reductions: 5-7 launches, 4 T^2 doubles of workspace per item, 0.08 / 0.15 of the fp64 MFMA peak,
+// and ~0.5 ms of pure launch latency for the handful of items the online step asks for).  Both terms are traces
+//     tr(X^T G^-1 Y) = sum (L^-1 X) o (L^-1 Y),   G = L L^T,
+// and a forward solve acts on the columns of its right-hand side independently.  So:
+//   1. the workgroup factors G cooperatively (Coop<NB>, tile_f64.hpp) and leaves L in the workspace in MFMA OPERAND order
+//      (the accumulator tile of U_KJ is the A operand of L[J, K]: stored as it stands, 2 KB per tile, tile J (J - 1) / 2 + K)
+//      next to the inverses W_K of its diagonal blocks - 272 KB per item at T = 256, L2-resident;
+//   2. every wave then takes PAIRS of 16-column panels of the right-hand side and forward-solves them by blocks,
+//          Y[K] = W_K (B[K] - sum_{K' < K} L[K, K'] Y[K']),
+//      with the two panels' 32 tiles of Y in registers and L streamed once per pair through a ring of prefetched tiles (the stream
+//      is the storage order: one contiguous read of the packed factor per panel pair, 8 MFMAs per 2 KB);
+//   3. what the trace needs is reduced on the spot - Y never goes to memory for a9.
+//        a9:  D = M - m_mean, R = I, diagonal prior scale S (the hot path's case; everything else keeps the composition):
+//             out = -0.5 |L^-1 D|_F^2 - 0.5 sum_j S_jj |L^-1 e_j|^2:  nb/2 pairs of D panels + nb/2 pairs of identity panels
+//             (an identity panel J starts at block row J; its tiles above are zeros and are skipped), dealt to the waves in
+//             snake order.  5/3 T^3 flops executed = the yardstick's.
+//        a8:  Y = L^-1 A goes to the workspace (packed tiles), z = L^-1 r rides as one more panel, then the Gram form
+//             tr(A^T G^-1 A P) = sum_{I <= J} (Y^T Y)_IJ o (P_IJ + P_JI^T)  (7/3 T^3 flops instead of the 11/3 T^3 of solving A and A P).
+// Numerics: same factorisation kernel, same regularisation and the same operation order per tile as the composition's
+// potrf -> L^-1 -> product chain up to the association of the sums (forward substitution instead of an explicit inverse).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "hgp_internal.hpp"
+#include "tile_f64.hpp"
+
+using namespace hgp;
+
+namespace {
+
+struct MniwCoopArgs {
+  const double* M;        // [b,T,T]
+  const double* Sigma;    // [b,T,T]
+  const double* m_mean;   // [T,T] or [b,T,T] (prior_stride)
+  const double* scale;    // diagonal prior scale, same stride
+  long prior_stride;
+  int T, b;
+  double* out;
+  int32_t* info;
+  double* ws;             // per item: (NB (NB - 1) / 2 + NB) packed tiles of 256 doubles
+};
+
+template <int NB>
+constexpr size_t packed_doubles() { return (size_t)(NB * (NB - 1) / 2 + NB) * 256; }
+
+// Forward solve of the panel pair (J0, J0 + 1) against the packed factor.  RHS(K, p) -> tile K of panel p (accumulator layout);
+// DONE(K, Y0, Y1) consumes the finished tiles of block row K.  kmin: the first block row with a non-zero right-hand side.
+template <int NB, int PAN, class RhsFn, class DoneFn>
+__device__ __forceinline__ void solve_panels(const double* __restrict__ Lp, const double* __restrict__ Wp, int nb, int kmin, int lane,
+                                             RhsFn rhs, DoneFn done) {
+  constexpr int RING = 4;
+  constexpr int NTL = NB * (NB - 1) / 2;
+  d4 Y[PAN][NB];
+  d4 ring[RING];
+  d4 nx[PAN];                                                // right-hand-side tiles one block row ahead
+#pragma unroll
+  for (int p = 0; p < PAN; ++p) nx[p] = rhs(kmin, p);
+  // Block rows below kmin hold zeros in Y and are skipped altogether; from row kmin on EVERY tile of the packed factor is
+  // streamed in storage order (tile q = K (K - 1) / 2 + K'), so that the ring slot of a tile is a compile-time constant; the tiles
+  // (K, K' < kmin) of an identity panel are loaded and not multiplied (2 KB from L2 against 4 PAN MFMAs saved).
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+    if (K < nb && K >= kmin) {
+      const int qrow = K * (K - 1) / 2;
+      const d4* Lt = reinterpret_cast<const d4*>(Lp) + launder(lane);     // tile q: Lt[64 q]
+      const d4* Wt = reinterpret_cast<const d4*>(Wp) + launder(lane);
+      if (K == kmin) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i)
+          if (qrow + i < NTL) ring[(qrow + i) % RING] = Lt[(size_t)64 * (qrow + i)];
+      }
+      d4 a[PAN];
+#pragma unroll
+      for (int p = 0; p < PAN; ++p) a[p] = nx[p];
+      if (K + 1 < nb) {
+#pragma unroll
+        for (int p = 0; p < PAN; ++p) nx[p] = rhs(K + 1, p);
+      }
+      const d4 wk = Wt[(size_t)64 * K];
+#pragma unroll
+      for (int Kp = 0; Kp < K; ++Kp) {
+        const int q = qrow + Kp;
+        const d4 lt = ring[q % RING];
+        if (q + RING < NTL) ring[q % RING] = Lt[(size_t)64 * (q + RING)];
+        if (Kp >= kmin) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int p = 0; p < PAN; ++p) a[p] = mfma_sub(lt[s], Y[p][Kp][s], a[p]);
+          }
+        }
+      }
+      d4 y[PAN];
+#pragma unroll
+      for (int p = 0; p < PAN; ++p) y[p] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int p = 0; p < PAN; ++p) y[p] = mfma(wk[s], a[p][s], y[p]);
+      }
+#pragma unroll
+      for (int p = 0; p < PAN; ++p) Y[p][K] = y[p];
+      done(K, y);
+    } else {
+#pragma unroll
+      for (int p = 0; p < PAN; ++p) Y[p][K] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_coop_mniw(MniwCoopArgs a) {
+  using C = Coop<NB>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* rowbuf = smem;
+  double* Rbuf = rowbuf + NB * 256;
+  double* Wbuf = Rbuf + NB * 256;
+  double* scr = Wbuf + 256;
+  double* red = scr + DIAG_SCR;
+  int* redi = reinterpret_cast<int*>(red + 8);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int m = blockIdx.x;
+  const int T = a.T;
+  const long tt = (long)T * T;
+  double* Lp = a.ws + (size_t)m * packed_doubles<NB>();
+  double* Wp = Lp + (size_t)(NB * (NB - 1) / 2) * 256;
+  int info;
+  {
+    d4 U[C::NT];
+    coop_load_sym_upper<NB>(U, a.Sigma + (size_t)m * tt, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
+    __syncthreads();   // rowbuf served as per-wave staging for the loader
+    coop_add_diag<NB>(U, 1e-8, T, wave, lane);        // chol(0.5 (S + S^T) + 1e-8 I), GPI_model.py:1353
+    PivotAcc pa;
+    pa.init();
+    coop_factor<NB, 0>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T, nullptr, nullptr, 0, Lp, Wp);
+    (void)coop_logdet_info(pa, wave, lane, red, redi, info);
+  }
+  __threadfence();     // the packed factor is read back through L2 by all four waves
+  __syncthreads();
+  const int nb = (T + 15) >> 4;
+  const int g = lane >> 4, c = lane & 15;
+  const double* Mm = a.M + (size_t)m * tt;
+  const double* mean = a.m_mean + (size_t)m * a.prior_stride;
+  const double* scale = a.scale + (size_t)m * a.prior_stride;
+  constexpr int PAN = 2;     // panels solved side by side by a wave (the spills of the NB = 16 instance are the factorisation's, as in k_coop_potrf<16>)
+  const int ngrp = (nb + PAN - 1) / PAN;
+  double acc = 0.0;
+  // D panels: groups w, w + 4, ...
+  for (int pp = wave; pp < ngrp; pp += WAVES) {
+    const int J0 = PAN * pp;
+    auto rhs = [&](int K, int p) {
+      d4 v;
+      const int ln = launder(lane);         // keeps the tile addresses of the unrolled solve out of the preheader
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * K + (ln >> 4) + 4 * r, j = 16 * (J0 + p) + (ln & 15);
+        v[r] = (i < T && j < T) ? Mm[(size_t)i * T + j] - mean[(size_t)i * T + j] : 0.0;
+      }
+      return v;
+    };
+    auto done = [&](int, const d4 (&y)[PAN]) {
+#pragma unroll
+      for (int p = 0; p < PAN; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = fma(y[p][r], y[p][r], acc);
+    };
+    solve_panels<NB, PAN>(Lp, Wp, nb, 0, lane, rhs, done);
+  }
+  // identity panels: sum_j S_jj |L^-1 e_j|^2; panel J costs (nb - J)^2 / 2 tile products: groups dealt in snake order
+  for (int t = 0; t < (ngrp + WAVES - 1) / WAVES; ++t) {
+    const int pp = (t & 1) ? (t + 1) * WAVES - 1 - wave : t * WAVES + wave;
+    if (pp >= ngrp) continue;
+    const int J0 = PAN * pp;
+    double sj[PAN];
+#pragma unroll
+    for (int p = 0; p < PAN; ++p) {
+      const int j = 16 * (J0 + p) + c;
+      sj[p] = (j < T) ? scale[(size_t)j * T + j] : 0.0;
+    }
+    auto rhs = [&](int K, int p) {
+      d4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (K == J0 + p && g + 4 * r == c) ? 1.0 : 0.0;
+      return v;
+    };
+    auto done = [&](int, const d4 (&y)[PAN]) {
+#pragma unroll
+      for (int p = 0; p < PAN; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = fma(sj[p] * y[p][r], y[p][r], acc);
+    };
+    solve_panels<NB, PAN>(Lp, Wp, nb, J0, lane, rhs, done);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    a.out[m] = (info != 0) ? __builtin_nan("") : -0.5 * tot;
+    if (a.info) a.info[m] = info;
+  }
+}
+
+template <int NB>
+int launch_coop_mniw(const MniwCoopArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_mniw<NB>), lds)) return rc_;
+  hipLaunchKernelGGL(k_coop_mniw<NB>, dim3(a.b), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
+}  // namespace
+
+size_t hgp_internal_matlik_coop_ws_doubles(int T) { return T <= 192 ? packed_doubles<12>() : packed_doubles<16>(); }
+
+// a9, identity right covariance and diagonal prior scale, 128 < T <= 256
+int hgp_internal_mniw_coop(const double* M, const double* Sigma, const double* m_mean, const double* scale, long prior_stride, int T, int b,
+                           double* out, int32_t* info, double* ws, hipStream_t st) {
+  MniwCoopArgs a{M, Sigma, m_mean, scale, prior_stride, T, b, out, info, ws};
+  return T <= 192 ? launch_coop_mniw<12>(a, st) : launch_coop_mniw<16>(a, st);
+}

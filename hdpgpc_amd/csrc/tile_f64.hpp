@@ -1114,7 +1114,11 @@ __device__ __forceinline__ void coop_add_diag(d4 (&U)[Coop<NB>::NT], double shif
 template <int NB, int RHSMODE>
 __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbuf, double* Rbuf, double* Wbuf, double* scr,
                                               int wave, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n,
-                                              double* dvec = nullptr, double* Wout = nullptr, int ldw = 0) {
+                                              double* dvec = nullptr, double* Wout = nullptr, int ldw = 0,
+                                              double* Lpack = nullptr, double* Wpack = nullptr) {
+  // Lpack / Wpack (optional): the factor in MFMA OPERAND order for a consumer that streams it (hgp_matlik_coop.hip) - the
+  // accumulator tile of U_KJ (K < J) IS the A operand of L[J, K] = U_KJ^T, so it is stored as it stands, 32 bytes per lane, at
+  // tile index J (J - 1) / 2 + K; the inverses W_K of the diagonal blocks (A-operand order already) at tile index K of Wpack.
   // Wout (optional): the inverses W_K = L_KK^{-1} of the diagonal blocks go to the diagonal blocks of this [n, ldw] matrix -
   // they ARE the diagonal blocks of L^{-1}; k_trtri (hgp_kernels.hip) fills in the rest from L.
   using C = Coop<NB>;
@@ -1145,6 +1149,7 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
           if (row < n && col < n) Wout[(size_t)row * ldw + col] = Wd[s];
         }
       }
+      if (Wpack != nullptr) *reinterpret_cast<d4*>(Wpack + ((size_t)K * 64 + lane) * 4) = Wd;
       if (RHS) {   // Z_K = W R_K
         const d4 rk = lds_tile_load(Rbuf, K, lane);
         d4 z = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1188,6 +1193,7 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
             if (row < n && col < n) Lout[(size_t)row * ldl + col] = acc[r];
           }
         }
+        if (Lpack != nullptr) *reinterpret_cast<d4*>(Lpack + ((size_t)(J * (J - 1) / 2 + K) * 64 + lane) * 4) = acc;
       }
     }
     if (RHSMODE == 2) {   // d_J -= U_KJ^T z_K for my columns J > K (nobody else touches those 16 entries)
