@@ -347,13 +347,14 @@ def secondary_matrix_terms(dev, ops, b=16384, T=90, reps=5):
     gb8 = b * (3.0 * T * T + 2 * T) * 8 / (ms8 * 1e-3) / 1e9
     gb9 = b * 2.0 * T * T * 8 / (ms9 * 1e-3) / 1e9
     if T > 128:
-        # the compositions at these sizes are bound by the matrix core, not by HBM (a8: potrf T^3/3 + L^-1 T^3/3 + Z A T^3 +
-        # (Z A) P 2 T^3 = 11/3 T^3 flops for 3 T^2 doubles: 39 flop/byte at T = 256 against a ridge of 9.8); a9 with the diagonal
-        # prior scale: 5/3 T^3.  At 100 % of the fp64 MFMA peak a8 would reach 1.28 M evals/s at T = 256, a9 2.8 M.
+        # these sizes are bound by the matrix core, not by HBM.  Yardstick (the reference's operation count, kept from round 3): a8
+        # factor T^3/3 + solve A T^3 + solve A P T^3 + the product A P 2 T^3 ... = 11/3 T^3 flops for 3 T^2 doubles (39 flop/byte at
+        # T = 256 against a ridge of 9.8), a9 with the diagonal prior scale 5/3 T^3.  The fused cooperative kernels of round 4
+        # (hgp_matlik_coop.hip) EXECUTE 5/3 T^3 for a9 and 7/3 T^3 for a8 (Gram form: factor, one solve, Y^T Y by symmetry).
         tf8 = b * (11.0 / 3.0) * T ** 3 / (ms8 * 1e-3) / 1e12
         tf9 = b * (5.0 / 3.0) * T ** 3 / (ms9 * 1e-3) / 1e12
-        return {"workload": f"{b} items, T={T}: a8 / a9 as compositions (cooperative Cholesky, L^-1 by block columns from L (k_trtri), "
-                            "triangular products, column norms for the diagonal prior scale)",
+        return {"workload": f"{b} items, T={T}: a8 / a9 as ONE cooperative launch each (k_coop_lat / k_coop_mniw: factor once, packed factor "
+                            "in the workspace, forward solves by panel pairs, reductions fused; a8 in Gram form: 7/3 T^3 executed)",
                 "a8": {"value": b / (ms8 * 1e-3), "unit": "evals/s", "kernel_ms": ms8,
                        "roofline": {"bound": "mfma", "achieved": tf8, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": tf8 / FP64_MFMA_PEAK_TFLOPS, "flops_per_eval": (11.0 / 3.0) * T ** 3, "hbm_GBps": gb8}},
@@ -502,8 +503,6 @@ def main():
             res["secondary_rank1"] = secondary_rank1(dev, ops)
             res["secondary_matrix_terms"] = secondary_matrix_terms(dev, ops)
             big = secondary_matrix_terms(dev, ops, b=256, T=256, reps=3)       # configs[4]'s size: composition of batched kernels
-            big["workload"] = ("256 items, T=256: a8 / a9 as compositions (cooperative Cholesky, L^-1 by block columns from L "
-                               "(k_trtri), triangular products, column norms for the diagonal prior scale)")
             res["secondary_matrix_terms_T256"] = big
             if not args.no_offline:
                 res["offline_r100"] = secondary_offline(dev, "100", 119.5, "configs[0]")

@@ -86,6 +86,9 @@ int hgp_internal_mniw_wave(const double* M, const double* Sigma, const double* m
 
 // hgp_matlik_coop.hip: the same two terms for 128 < T <= HGP_MAX_T_COOP, one workgroup per item (factor once, packed factor in ws)
 size_t hgp_internal_matlik_coop_ws_doubles(int T);
+size_t hgp_internal_lat_coop_ws_doubles(int T);
+int hgp_internal_lat_coop(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* P, int T, int b,
+                          double* out, int32_t* info, double* ws, hipStream_t st);
 int hgp_internal_mniw_coop(const double* M, const double* Sigma, const double* m_mean, const double* scale, long prior_stride, int T, int b,
                            double* out, int32_t* info, double* ws, hipStream_t st);
 

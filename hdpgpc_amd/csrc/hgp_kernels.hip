@@ -2013,8 +2013,11 @@ int hgp_lat_error_f64(const double* f_cur, const double* f_prev, const double* A
   if (T > HGP_MAX_T_COOP) return -2;
   if (T <= HGP_MAX_T_WAVE)   // fused: one wavefront per item, nothing goes through the workspace
     return hgp_internal_lat_error_wave(f_cur, f_prev, A, Gamma, covprev, T, b, out, info, (hipStream_t)stream);
-  if (!ws || ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;   // 128 < T <= 256: composition of the batched kernels
+  if (!ws || ws_bytes < hgp_matrix_lik_ws_bytes(T, b)) return -1;
   hipStream_t st = (hipStream_t)stream;
+  if (!env_on("HGP_MATLIK_COMPOSE"))   // 128 < T <= 256: one fused cooperative kernel per item, Gram form (hgp_matlik_coop.hip)
+    return hgp_internal_lat_coop(f_cur, f_prev, A, Gamma, covprev, T, b, out, info, (double*)ws, st);
+  // (kept for A/B runs: the composition of the batched kernels)
   const long tt = (long)T * T;
   double* Gc = (double*)ws;          // copy of Gamma -> L
   double* Z = Gc + (size_t)b * tt;   // L^{-1}

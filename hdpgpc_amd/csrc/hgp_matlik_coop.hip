@@ -214,7 +214,219 @@ int launch_coop_mniw(const MniwCoopArgs& a, hipStream_t st) {
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------ a8
+struct LatCoopArgs {
+  const double* f_cur;    // [b,T]
+  const double* f_prev;   // [b,T]
+  const double* A;        // [b,T,T]
+  const double* Gamma;    // [b,T,T]
+  const double* P;        // [b,T,T]  covariance of the previous state
+  int T, b;
+  double* out;
+  int32_t* info;
+  double* ws;             // per item: packed factor (NB (NB - 1) / 2 + NB tiles) + NB * NB packed tiles of Y = L^-1 A
+};
+
+template <int NB>
+constexpr size_t lat_ws_doubles() { return packed_doubles<NB>() + (size_t)NB * NB * 256; }
+
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_coop_lat(LatCoopArgs a) {
+  using C = Coop<NB>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* rowbuf = smem;
+  double* Rbuf = rowbuf + NB * 256;
+  double* Wbuf = Rbuf + NB * 256;
+  double* scr = Wbuf + 256;
+  double* red = scr + DIAG_SCR;
+  int* redi = reinterpret_cast<int*>(red + 8);
+  double* rvec = smem + C::LDS_DOUBLES;              // [16 NB]: r = f_cur - A f_prev (zero padded)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int m = blockIdx.x;
+  const int T = a.T;
+  const long tt = (long)T * T;
+  const int nb = (T + 15) >> 4;
+  double* Lp = a.ws + (size_t)m * lat_ws_doubles<NB>();
+  double* Wp = Lp + (size_t)(NB * (NB - 1) / 2) * 256;
+  double* Yp = Lp + packed_doubles<NB>();            // tile (K, J) at K * NB + J, accumulator layout
+  const double* Am = a.A + (size_t)m * tt;
+  // r = f_cur - A f_prev on the VALU: wave w takes the rows w, w + 4, ... (64 consecutive elements per load, one wave reduction per row)
+  {
+    const double* fp = a.f_prev + (size_t)m * T;
+    const double* fc = a.f_cur + (size_t)m * T;
+    double fpv[NB / 4];
+#pragma unroll
+    for (int u = 0; u < NB / 4; ++u) fpv[u] = (64 * u + lane < T) ? fp[64 * u + lane] : 0.0;
+    for (int i = wave; i < 16 * NB; i += WAVES) {
+      double sacc = 0.0;
+      if (i < T) {
+#pragma unroll
+        for (int u = 0; u < NB / 4; ++u) sacc = fma((64 * u + lane < T) ? Am[(size_t)i * T + 64 * u + lane] : 0.0, fpv[u], sacc);
+      }
+      sacc = wave_sum(sacc);
+      if (lane == 0) rvec[i] = (i < T) ? fc[i] - sacc : 0.0;
+    }
+  }
+  int info;
+  {
+    d4 U[C::NT];
+    coop_load_sym_upper<NB>(U, a.Gamma + (size_t)m * tt, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
+    __syncthreads();   // rowbuf served as per-wave staging for the loader
+    {                  // _chol_spd(Gamma): + 1e-8 max(mean |diag|, eps) I  (GPI_model.py:83-87,312)
+      const double dm = coop_diag_abs_mean<NB>(U, T, wave, lane, 0.0, red);
+      coop_add_diag<NB>(U, 1e-8 * fmax(dm, F64_EPS), T, wave, lane);
+    }
+    __syncthreads();
+    PivotAcc pa;
+    pa.init();
+    coop_factor<NB, 0>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T, nullptr, nullptr, 0, Lp, Wp);
+    (void)coop_logdet_info(pa, wave, lane, red, redi, info);
+  }
+  __threadfence();
+  __syncthreads();
+  constexpr int PAN = 2;
+  const int ngrp = (nb + PAN - 1) / PAN;
+  double acc = 0.0;
+  // Y = L^-1 A by panel pairs, stored as packed accumulator tiles
+  for (int pp = wave; pp < ngrp; pp += WAVES) {
+    const int J0 = PAN * pp;
+    auto rhs = [&](int K, int p) {
+      d4 v;
+      const int ln = launder(lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * K + (ln >> 4) + 4 * r, j = 16 * (J0 + p) + (ln & 15);
+        v[r] = (i < T && j < T) ? Am[(size_t)i * T + j] : 0.0;
+      }
+      return v;
+    };
+    auto done = [&](int K, const d4 (&y)[PAN]) {
+      const int ln = launder(lane);
+#pragma unroll
+      for (int p = 0; p < PAN; ++p)
+        if (J0 + p < NB) *reinterpret_cast<d4*>(Yp + ((size_t)(K * NB + J0 + p) * 64 + ln) * 4) = y[p];
+    };
+    solve_panels<NB, PAN>(Lp, Wp, nb, 0, lane, rhs, done);
+  }
+  // z = L^-1 r (one more panel, column 0; the wave with the fewest panel pairs takes it)
+  if (wave == (ngrp % WAVES)) {
+    auto rhs = [&](int K, int) {
+      d4 v;
+      const int ln = launder(lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = ((ln & 15) == 0) ? rvec[16 * K + (ln >> 4) + 4 * r] : 0.0;
+      return v;
+    };
+    auto done = [&](int, const d4 (&y)[1]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = fma(y[0][r], y[0][r], acc);
+    };
+    solve_panels<NB, 1>(Lp, Wp, nb, 0, lane, rhs, done);
+  }
+  __threadfence();
+  __syncthreads();
+  // Gram form: tr(A^T G^-1 A P) = sum_{I <= J} (Y^T Y)_IJ o Pw_IJ,  Pw_IJ = P_IJ + P_JI^T (I < J), P_II (I = J).
+  // 2 x 2 blocks of tile pairs per step: four tiles of Y per block row feed sixteen MFMAs.
+  {
+    const double* Pm = a.P + (size_t)m * tt;
+    const int nb2 = (nb + 1) >> 1;
+    const int nblk = nb2 * (nb2 + 1) / 2;
+    double* scw = scr;                               // this wave's 16 x 18 staging tile (transposes of P)
+    scw = rowbuf + wave * DIAG_SCR;
+    for (int t = wave; t < nblk; t += WAVES) {
+      int Ib = 0, rem = t;                           // block (Ib, Jb), Ib <= Jb, row-major over the upper triangle
+      while (rem >= nb2 - Ib) {
+        rem -= nb2 - Ib;
+        ++Ib;
+      }
+      const int Jb = Ib + rem;
+      const int I0 = 2 * Ib, J0 = 2 * Jb;
+      d4 G[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) G[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+      const d4* Yt = reinterpret_cast<const d4*>(Yp) + lane;
+      d4 yi[2], yj[2], ni[2], nj[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        ni[x] = Yt[(size_t)64 * (0 * NB + I0 + x)];
+        nj[x] = Yt[(size_t)64 * (0 * NB + J0 + x)];
+      }
+      for (int K = 0; K < nb; ++K) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          yi[x] = ni[x];
+          yj[x] = nj[x];
+        }
+        if (K + 1 < nb) {
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            ni[x] = Yt[(size_t)64 * ((K + 1) * NB + I0 + x)];
+            nj[x] = Yt[(size_t)64 * ((K + 1) * NB + J0 + x)];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) G[x][y] = mfma(yi[x][s], yj[y][s], G[x][y]);
+      }
+      const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          const int I = I0 + x, J = J0 + y;
+          if (I > J || J >= nb) continue;            // lower tile of a diagonal block / padding
+          d4 pn, pt;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + g + 4 * r, j = 16 * J + c;
+            pn[r] = (i < T && j < T) ? Pm[(size_t)i * T + j] : 0.0;
+            const int i2 = 16 * J + g + 4 * r, j2 = 16 * I + c;
+            pt[r] = (I < J && i2 < T && j2 < T) ? Pm[(size_t)i2 * T + j2] : 0.0;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scw[(g + 4 * r) * DIAG_LD + c] = pt[r];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = fma(G[x][y][r], pn[r] + scw[c * DIAG_LD + g + 4 * r], acc);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  __syncthreads();
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    a.out[m] = (info != 0) ? __builtin_nan("") : -0.5 * tot;
+    if (a.info) a.info[m] = info;
+  }
+}
+
+template <int NB>
+int launch_coop_lat(const LatCoopArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(double) * (Coop<NB>::LDS_DOUBLES + 16 * NB);
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_lat<NB>), lds)) return rc_;
+  hipLaunchKernelGGL(k_coop_lat<NB>, dim3(a.b), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
 }  // namespace
+
+size_t hgp_internal_lat_coop_ws_doubles(int T) { return T <= 192 ? lat_ws_doubles<12>() : lat_ws_doubles<16>(); }
+
+// a8, 128 < T <= 256
+int hgp_internal_lat_coop(const double* f_cur, const double* f_prev, const double* A, const double* Gamma, const double* P, int T, int b,
+                          double* out, int32_t* info, double* ws, hipStream_t st) {
+  LatCoopArgs a{f_cur, f_prev, A, Gamma, P, T, b, out, info, ws};
+  return T <= 192 ? launch_coop_lat<12>(a, st) : launch_coop_lat<16>(a, st);
+}
 
 size_t hgp_internal_matlik_coop_ws_doubles(int T) { return T <= 192 ? packed_doubles<12>() : packed_doubles<16>(); }
 

@@ -24,7 +24,7 @@ def spd(rng, b, T, scale=1.0):
     return scale * (Q @ Q.transpose(0, 2, 1) / T + np.eye(T) * rng.uniform(0.2, 1.0, (b, 1, 1)))
 
 
-@pytest.mark.parametrize("T,b", [(8, 3), (33, 5), (64, 4), (90, 37), (128, 6), (144, 2), (256, 2)])
+@pytest.mark.parametrize("T,b", [(8, 3), (33, 5), (64, 4), (90, 37), (128, 6), (129, 2), (144, 2), (200, 5), (256, 2), (256, 9)])
 def test_lat_error_a8(T, b):
     rng = np.random.default_rng(T)
     A = np.eye(T)[None] + 0.05 * rng.normal(size=(b, T, T))
@@ -37,8 +37,8 @@ def test_lat_error_a8(T, b):
     assert rel_err(out.cpu().numpy() - 0.5 * T * orc.LOG2PI, ref) < 1e-9
 
 
-@pytest.mark.parametrize("T,b", [(8, 3), (33, 5), (64, 4), (90, 37), (128, 6), (144, 2), (256, 2)])
-@pytest.mark.parametrize("prior", ["shared_identity", "per_item_dense"])
+@pytest.mark.parametrize("T,b", [(8, 3), (33, 5), (64, 4), (90, 37), (128, 6), (129, 2), (144, 2), (200, 5), (256, 2), (256, 9)])
+@pytest.mark.parametrize("prior", ["shared_identity", "per_item_diagonal", "per_item_dense"])
 def test_mniw_loglik_a9(T, b, prior):
     rng = np.random.default_rng(1000 + T)
     M = np.eye(T)[None] + 0.05 * rng.normal(size=(b, T, T))
@@ -47,12 +47,32 @@ def test_mniw_loglik_a9(T, b, prior):
         mm, R, S = np.eye(T) * 0.9, None, np.diag(rng.uniform(0.5, 3.0, T))
         out, info = ops.mniw_loglik(dev(M), dev(Sig), dev(mm), None, dev(S))
         ref = np.array([orc.mniw_log_likelihood(M[i], Sig[i], mm, np.eye(T), S) for i in range(b)])
+    elif prior == "per_item_diagonal":  # every item its own prior mean and diagonal scale (the online step's batched candidates)
+        mm = 0.1 * rng.normal(size=(b, T, T))
+        S = np.stack([np.diag(rng.uniform(0.5, 3.0, T)) for _ in range(b)])
+        out, info = ops.mniw_loglik(dev(M), dev(Sig), dev(mm), None, dev(S), scale_is_diagonal=True)
+        ref = np.array([orc.mniw_log_likelihood(M[i], Sig[i], mm[i], np.eye(T), S[i]) for i in range(b)])
     else:
         mm, R, S = 0.1 * rng.normal(size=(b, T, T)), spd(rng, b, T), spd(rng, b, T, 3.0)
         out, info = ops.mniw_loglik(dev(M), dev(Sig), dev(mm), dev(R), dev(S))
         ref = np.array([orc.mniw_log_likelihood(M[i], Sig[i], mm[i], R[i], S[i]) for i in range(b)])
     assert int(info.abs().max()) == 0
     assert rel_err(out.cpu().numpy(), ref) < 1e-9
+
+
+def test_matlik_coop_reports_non_spd_items():
+    """The fused cooperative kernels (128 < T <= 256): LAPACK-style info per item, NaN in the output of a failed item only."""
+    rng = np.random.default_rng(6)
+    T, b = 200, 4
+    Gam = spd(rng, b, T)
+    Gam[1, 150, 150] = -3.0
+    A = np.tile(np.eye(T), (b, 1, 1))
+    out, info = ops.lat_error(dev(rng.normal(size=(b, T))), dev(rng.normal(size=(b, T))), dev(A), dev(Gam), dev(spd(rng, b, T)))
+    info, out = info.cpu().numpy(), out.cpu().numpy()
+    assert info[1] > 0 and np.all(np.delete(info, 1) == 0) and np.isnan(out[1]) and np.all(np.isfinite(np.delete(out, 1)))
+    out, info = ops.mniw_loglik(dev(A), dev(Gam), dev(np.eye(T)), None, dev(2.0 * np.eye(T)), scale_is_diagonal=True)
+    info, out = info.cpu().numpy(), out.cpu().numpy()
+    assert info[1] > 0 and np.all(np.delete(info, 1) == 0) and np.isnan(out[1]) and np.all(np.isfinite(np.delete(out, 1)))
 
 
 def test_matlik_reports_non_spd_items():
