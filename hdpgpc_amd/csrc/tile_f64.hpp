@@ -517,6 +517,13 @@ __device__ __forceinline__ d4 diag16_col(const d4& X, double* scr, int lane, Piv
 // of the symmetric Schur complement never reach a live entry).  ~470 instructions per block, dependency chain ~80 cycles per pivot.
 // Same interface as the other forms; results agree to rounding (multipliers S/p instead of (S/sqrt p)(S/sqrt p)).
 // ---------------------------------------------------------------------------------------------
+#ifndef HGP_DIAG_SCHED
+#define HGP_DIAG_SCHED 0     // 0 = the compiler's schedule (shipped); 2 = scheduling barriers keep the off-chain FMAs behind the next pivot's
+                             // broadcasts; 1 / 3 = fully pinned orders.  Round 4 measured all four (tools/probe_diag16, tools/ab_sched.sh,
+                             // profiles/r04_ab_sched.txt): 3 088 / 3 004 / 3 144 / 3 388 cycles per block in isolation, and NO difference
+                             // inside the kernels (k_pairs<8> 1.000-1.023 ms in every variant): the block is bound by its ~25
+                             // instructions per pivot, not by where they sit
+#endif
 template <int G0>
 __device__ __forceinline__ double row_to_all(double v) {   // row G0 (16 lanes) of v copied to all four rows of the wave
   const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
@@ -596,6 +603,54 @@ __device__ __forceinline__ d4 diag16_acc(const d4& X, double* scr, int lane, Piv
   const int crot = (c + g) & 15;
   double p = lane_bcast(S[0], 0);
   double sk = row_to_all_bperm(S[0], 4 * c), mrot = row_to_all_bperm(S[0], 4 * crot), zk = row_to_all_bperm(Z[0], 4 * c);
+#if HGP_DIAG_SCHED
+  // Round 4: the step's instruction ORDER is pinned.  A wave issues in order, so where the machine scheduler put things decided the
+  // step: (a) it moved the off-chain FMAs (elim_rest, an opaque asm block) in front of the next pivot's v_readlane and the six
+  // ds_bpermute - ~50 cycles back on the pivot chain; (b) with that fixed, the six crossbar instructions (~10 cycles of issue each)
+  // still sat in one run in front of the reciprocal.  Here the pivot is read first, and the crossbar instructions are dealt into
+  // the latency gaps of the reciprocal's dependent chain (v_rcp 21 cycles, each dependent f64 operation ~9.5: measured in
+  // tools/probe_lat.hip), two per gap, in the order their results are needed (s_k, z_k, then the rotated copy for the FMAs).
+  double rp = rcp_nr(p);
+  static_for<0, 15>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, r0 = k >> 2, g0 = k & 3;
+    constexpr int RS = (g0 == 3) ? r0 + 1 : r0;                          // register of row k + 1
+    constexpr int RMF = (g0 == 3) ? 0xf : (0xf << (g0 + 1)) & 0xf;      // its rows below the pivot
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(k));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(k));
+    if (Lout != nullptr) Us[r0] = (g == g0) ? sk : Us[r0];
+    const double nt = -(sk * rp), ntz = -(zk * rp), mr = mrot;
+    elim_crit<RS, RMF>(S, Z, mr, nt, ntz);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int k1 = k + 1, g1 = k1 & 3;
+    p = lane_bcast(S[RS], 16 * g1 + k1);
+    if constexpr (k1 < 15) {
+      const double y = __builtin_amdgcn_rcp(p);
+      sk = row_to_all_bperm(S[RS], 4 * (16 * g1 + c));
+      const double e = fma(-p, y, 1.0);
+      zk = row_to_all_bperm(Z[RS], 4 * (16 * g1 + c));
+      const double ye = y * e;
+      mrot = row_to_all_bperm(S[RS], 4 * (16 * g1 + crot));
+      rp = fma(ye, e, y + ye);
+#if HGP_DIAG_SCHED == 1      // 2 v_readlane + v_rcp | 6 DS | the reciprocal's dependent operations
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x080, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#elif HGP_DIAG_SCHED == 3    // the crossbar instructions dealt into the gaps of the reciprocal's chain, two per gap
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+#endif                       // 2: only the two scheduling barriers around the block (the compiler orders the inside)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    elim_rest<RS>(S, Z, mr, nt, ntz);
+  });
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(15));
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(15));
+#else
   static_for<0, 15>([&](auto kc) {
     constexpr int k = decltype(kc)::value, r0 = k >> 2, g0 = k & 3;
     constexpr int RS = (g0 == 3) ? r0 + 1 : r0;                          // register of row k + 1
@@ -617,6 +672,7 @@ __device__ __forceinline__ d4 diag16_acc(const d4& X, double* scr, int lane, Piv
   });
   asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(15));
   asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(15));
+#endif
   if (Lout != nullptr) Us[3] = (g == 3) ? S[3] : Us[3];
   // the pivots: lane c of row 0 holds p_c; every row needs it for the scaling of its part of W
   const double pv = row_to_all<0>(__hiloint2double(pvhi, pvlo));
