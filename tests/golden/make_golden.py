@@ -831,6 +831,41 @@ def gen_cluster_learning(tag, rec, n0, n1, leads=(0, 1), n_explore=5):
           f"events={len(order)} err={err}")
 
 
+# ------------------------------------- the gpytorch fit - the only numbers the reference HOLDS for it
+def gen_kernel_fit_notebook():
+    """gpytorch is absent here, so the fit cannot be run; but hdpgpc/tests/test_step.ipynb stores the printed output of four
+    fits of the reference's own run (loss every 500 iterations to 3 decimals, the four raw gpytorch parameters after the 4000th
+    step to 8+ digits).  This copies those NUMBERS (and which beat each fit saw) into a fixture: data, not code."""
+    import json
+    import re
+    nb = json.load(open(os.path.join(REF, "tests", "test_step.ipynb")))
+    fits = []
+    for i, c in enumerate(nb["cells"]):
+        if c["cell_type"] != "code":
+            continue
+        txt = "".join("".join(o.get("text") or o.get("data", {}).get("text/plain") or []) for o in c.get("outputs", []))
+        for m in re.finditer(r"(?:Sample: (\d+) /[^\n]*\n(?:[^\n]*\n){0,3})?\s*Fitting_GP:(.*?)raw_lengthscale\s+value = \[\[([-\d.e]+)\]\]", txt, re.S):
+            blk = m.group(2)
+            losses = re.findall(r"Iter (\d+)/4000 - Loss: ([\d.]+)", blk)
+            vals = re.findall(r"value = \[?([-\d.e]+)", blk)
+            fits.append((i, m.group(1), [int(a) for a, _ in losses], [float(b) for _, b in losses], [float(v) for v in vals] + [float(m.group(3))]))
+    assert [f[0] for f in fits] == [22, 26, 33, 36], fits
+    fits = fits[:3]
+    # cell 4: data = record 100 [1700:1950]; cells 22 / 26 / 33 fit data_[0], data_[5], data_[206] (lead 0) with the white-kernel
+    # bounds (std 0.1, std 0.2), std = compute_estimators_LDS(data, n_f = 50) (cell 8 prints 11.558797835735662).  Cell 36 (the
+    # first fit inside include_batch with reestimate_initial_params) is left out: no beat of the record reproduces its first loss
+    # (472.718) under the bounds today's redefine_default would set - the notebook ran an older revision of that re-estimation
+    data = np.load(os.path.join(REF, "data", "mitbih", "100.npy"))
+    # (the number the NOTEBOOK printed in cell 8: today's compute_estimators_LDS returns another estimate for the same beats)
+    cell8 = "".join("".join(o.get("text") or []) for o in nb["cells"][8].get("outputs", []))
+    std = float(re.search(r"Sigma estimated: ([\d.]+)", cell8).group(1))
+    out = {"beats": np.array([1700, 1705, 1906]), "iters": np.array(fits[0][2]),
+           "losses": np.array([f[3] for f in fits]), "raw_final": np.array([f[4] for f in fits]),   # raw noise, mean, raw outputscale, raw lengthscale
+           "std_cell8": np.array(float(std)), "y": np.stack([data[b, :, 0] for b in (1700, 1705, 1906)])}
+    np.savez_compressed(os.path.join(OUT, "kernel_fit_notebook.npz"), **out)
+    print("kernel_fit_notebook:", out["losses"][:, [0, -1]], out["raw_final"], float(std))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gram", "score", "pred", "ill", "state", "lml", "warp", "offline"]
     if "gram" in which:
@@ -879,6 +914,8 @@ if __name__ == "__main__":
         gen_include_sample("r102_t256_n24", "102", 24, T_res=256)
     if "online256x2" in which:         # configs[4]: two records concatenated (16 beats of record 100, then 16 of record 102), T = 256
         gen_include_sample("r100_r102_t256_n32", ["100", "102"], 16, T_res=256)
+    if "fitnb" in which:
+        gen_kernel_fit_notebook()
     if "reload" in which:
         gen_reload("r102", "102")
     if "reload2" in which:

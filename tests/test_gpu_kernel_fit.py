@@ -20,25 +20,7 @@ if torch.cuda.is_available():
     from hdpgpc_amd.kernel_fit import fit_kernel_adam
 
 
-def numpy_adam(x, y, bounds, iters, lr=0.1):
-    sp = lambda v: math.log1p(math.exp(-abs(v))) + max(v, 0.0)  # noqa: E731
-    sg = lambda v: 1.0 / (1.0 + math.exp(-v))  # noqa: E731
-    lo, hi = bounds
-    T = x.size
-    p, m1, m2 = np.zeros(4), np.zeros(4), np.zeros(4)
-    losses = []
-    for it in range(1, iters + 1):
-        noise, c, ell = lo + (hi - lo) * sg(p[0]), sp(p[2]), sp(p[3])
-        r = y - p[1]
-        val, glog = orc.log_marginal_likelihood(x, r, (c, ell, noise), faithful=False, eval_gradient=True)
-        K = orc.gram_rbf(x, None, c, ell, noise)
-        sa = float(np.sum(np.linalg.solve(K, r)))
-        losses.append(-val / T)
-        g = np.array([glog[2] / noise * (hi - lo) * sg(p[0]) * (1 - sg(p[0])), sa, glog[0] / c * sg(p[2]), glog[1] / ell * sg(p[3])]) * (-1.0 / T)
-        m1 = 0.9 * m1 + 0.1 * g
-        m2 = 0.999 * m2 + 0.001 * g * g
-        p = p - lr * (m1 / (1 - 0.9 ** it)) / (np.sqrt(m2 / (1 - 0.999 ** it)) + 1e-8)
-    return (sp(p[2]), sp(p[3]), lo + (hi - lo) * sg(p[0]), p[1]), np.array(losses)
+from kernel_fit_ref import numpy_adam  # noqa: E402  (the restatement pinned by the reference's notebook output)
 
 
 def _beat():
@@ -57,6 +39,23 @@ def test_gpu_adam_matches_numpy_restatement():
     assert np.allclose(tr_g, tr_n, rtol=1e-7, atol=1e-9)
     assert np.allclose(th_g, th_n, rtol=1e-6)
     assert tr_g[-1] < tr_g[0]
+
+
+@pytest.mark.parametrize("i", [0, 2])
+def test_gpu_fit_reproduces_the_notebook_output(i):
+    """The reference's own printed fits (hdpgpc/tests/test_step.ipynb cells 22 / 33, tests/golden/kernel_fit_notebook.npz): the
+    GPU fit prints the same losses (three decimals) and ends at the same raw gpytorch parameters."""
+    g = golden("kernel_fit_notebook.npz")
+    y = g["y"][i]
+    x = np.arange(float(y.size))
+    s = float(g["std_cell8"])
+    (c, ell, noise, mean), tr = fit_kernel_adam(x, y, (0.1 * s, 0.2 * s), min_iter=10 ** 9, return_trace=True)
+    assert len(tr) == 4000
+    assert np.max(np.abs(tr[g["iters"] - 1] - g["losses"][i])) <= 6e-4
+    raw = g["raw_final"][i]
+    sp = lambda v: math.log1p(math.exp(-abs(v))) + max(v, 0.0)  # noqa: E731
+    want = (sp(raw[2]), sp(raw[3]), 0.1 * s + 0.1 * s / (1.0 + math.exp(-raw[0])), raw[1])
+    assert np.allclose((c, ell, noise, mean), want, rtol=1e-5)
 
 
 def test_fit_runs_the_reference_schedule_inside_bounds():
