@@ -33,7 +33,7 @@ raceprobe: $(SRCS) $(HDR)
 # every workgroup barrier followed by a pseudo-random per-wave delay: run the GPU tests with HGP_LIB pointing at it
 racestress: $(SRCS) $(HDR)
 	mkdir -p build/probe
-	$(HIPCC) $(FLAGS) -DHGP_RACE_STRESS -shared -o build/probe/libhgp_race_stress.so $(SRCS)
+	$(HIPCC) $(FLAGS) -DHGP_RACE_STRESS -shared -o hdpgpc_amd/lib/ab/libhgp_race_stress.so $(SRCS)
 
 # in-situ knock-out builds of k_pairs (results wrong by construction, only the time matters; tools/knockout_time.py):
 # one component replaced by a stub each - what the component costs INSIDE the kernel, not in isolation
