@@ -62,6 +62,11 @@ class IterativeGaussianProcess:
         self.verbose = verbose
         self.fitted = False
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["x_basis"] = self.x_basis.detach().cpu()
+        return d
+
     def cond_to_torch(self, x):
         if x is None:
             return None

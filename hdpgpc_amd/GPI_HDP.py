@@ -47,6 +47,21 @@ def _limit_host_threads():
         torch.set_num_threads(n)
 
 
+def _kernel_params(k):
+    """(output-scale, length-scale, noise level, noise bounds or None) of ConstantKernel * RBF + WhiteKernel (scikit-learn's
+    composition, GPI_HDP.py:164-166) or of an RBFWhiteKernel."""
+    if isinstance(k, RBFWhiteKernel):
+        return (k.constant_value, k.length_scale, k.noise_level, None)
+    try:
+        c = float(k.k1.k1.constant_value)
+        ell = float(np.asarray(k.k1.k2.length_scale).reshape(-1)[0])
+        nb = getattr(k.k2, "noise_level_bounds", None)
+        nb = None if nb is None or isinstance(nb, str) else (float(nb[0]), float(nb[1]))
+        return (c, ell, float(k.k2.noise_level), nb)
+    except AttributeError as e:
+        raise TypeError("kernels=: expected ConstantKernel * RBF + WhiteKernel (scikit-learn) or RBFWhiteKernel objects") from e
+
+
 def _first(v):
     """Per-cluster options may arrive as one value or as a list with one value per initial cluster (GPI_HDP.py:123-156)."""
     return v[0] if isinstance(v, (list, np.ndarray)) and np.ndim(v) > 0 else v
@@ -63,8 +78,16 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
                  max_models=None, batch=None, check_var=False, bayesian_params=True, cuda=False, inducing_points=False,
                  estimation_limit=None, reestimate_initial_params=False, n_explore_steps=10, free_deg_MNIV=5,
                  share_gp=False, use_snr=True, reduce_outputs=False, reduce_outputs_ratio=1.0, hdp_hyp='balanced'):
+        kern0 = None
         if kernels is not None:
-            raise NotImplementedError("explicit kernel objects: pass ini_outputscale / ini_lengthscale / bound_sigma instead")
+            # GPI_HDP.py:160-168 builds ConstantKernel(c, (c, 5 c)) * RBF(ell, bounds) + WhiteKernel(noise, bounds) per cluster when no
+            # kernels are given; explicit ones (scikit-learn objects of that shape, or RBFWhiteKernel) are read for their parameters.
+            # One kernel for all initial clusters (what every driver passes): per-cluster initial kernels are not built
+            ks = list(kernels) if isinstance(kernels, (list, tuple)) else [kernels]
+            pars = [_kernel_params(k) for k in ks]
+            if any(p_ != pars[0] for p_ in pars[1:]):
+                raise NotImplementedError("kernels=: different initial kernels per cluster are not part of this build")
+            kern0 = pars[0]
         if inducing_points or estimation_limit is not None:
             raise NotImplementedError("inducing points / estimation_limit are not part of this build")
         _limit_host_threads()
@@ -84,6 +107,10 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         osc = _first(ini_outputscale)
         self.ini_outputscale_def = self.ini_sigma_def if osc is None else float(osc)      # GPI_HDP.py:157-158
         self.ini_lengthscale, self.bound_lengthscale = _first(ini_lengthscale), bound_lengthscale
+        if kern0 is not None:      # explicit kernel: its output-scale, length-scale and white-noise bounds are the defaults
+            self.ini_outputscale_def, self.ini_lengthscale = kern0[0], kern0[1]
+            if kern0[3] is not None:
+                bound_sigma = kern0[3]
         self.bound_sigma_def = tuple(bound_sigma[0]) if isinstance(bound_sigma, list) else tuple(bound_sigma)
         self.bound_gamma_def = tuple(bound_gamma[0]) if isinstance(bound_gamma, list) else tuple(bound_gamma)
         self.annealing_def = bool(_first(annealing))
@@ -151,6 +178,45 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         if getattr(gpmodel, "_def_diag_key", None) == (id(g.Sigma_def), id(g.Gamma_def)):     # same prior objects: same verdict
             g._def_diag_key, g._def_diag = gpmodel._def_diag_key, gpmodel._def_diag
         return g
+
+    def keep_last_all(self):
+        """GPI_HDP.py:460-466: drop every cluster's history but its first and last entries."""
+        for ld in range(self.n_outputs):
+            for gp in self.gpmodels[ld]:
+                gp.reinit_LDS(save_last=True)
+                gp.reinit_GP(save_last=True, save_index=True)
+        self.__dict__.pop("_pools", None)       # the persistent chains of the online step held the dropped history
+
+    def save_swgp(self, st):
+        """GPI_HDP.py:3946-3950: keep_last_all, everything to host memory, pickle.  ``load_swgp`` (or pickle.load) brings it back
+        onto the default device."""
+        import pickle
+        self.keep_last_all()
+        with open(st, "wb") as f:
+            pickle.dump(self, f)
+
+    @staticmethod
+    def load_swgp(st):
+        import pickle
+        with open(st, "rb") as f:
+            return pickle.load(f)
+
+    def __getstate__(self):
+        # (the time-warp fitters are rebuilt on load: their warm-start controls are not part of the saved model)
+        d = {k: v for k, v in self.__dict__.items() if k not in ("_pools", "_lin_memo", "_warp_cache_full", "wp_sys")}
+        return _to_device(d, "cpu")
+
+    def __setstate__(self, d):
+        _limit_host_threads()
+        dev = self._default_device if torch.cuda.is_available() else "cpu"
+        self.__dict__.update(_to_device(d, dev))
+        self.device = dev
+        self._warp_cache_full = {}
+        for lead in self.gpmodels:
+            for g in lead:
+                g._set_device(dev)
+                g.theta_source = self
+        self.wp_sys = [[self.create_wp_sys_default() for _ in range(len(lead))] for lead in self.gpmodels]
 
     def selected_gpmodels(self):
         return list(range(sum(1 for g in self.gpmodels[0] if len(g.indexes) > 0)))
@@ -381,6 +447,19 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         fmsg, marg, bmsg, _ = self._messages(startPi, q_norm, False)
         self.last_messages = (fmsg, marg, bmsg)
         return ops.assign(fmsg, bmsg).cpu()           # = torch.where(_safe_exp(LogLik(log(alpha beta))) == 1)[1]
+
+
+def _to_device(o, dev, _seen=None):
+    """Tensors of a (nested) structure of dicts / lists / tuples moved to `dev`; everything else as it is."""
+    if torch.is_tensor(o):
+        return o.to(dev)
+    if isinstance(o, dict):
+        return {k: _to_device(v, dev) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_to_device(v, dev) for v in o]
+    if isinstance(o, tuple):
+        return tuple(_to_device(v, dev) for v in o)
+    return o
 
 
 def _np(a):

@@ -175,6 +175,48 @@ class GPI_model:
         self._pending = []
         self._defer_checks = False
 
+    # ------------------------------------------------------------------ pickling (GPI_HDP.save_swgp)
+    _TENSOR_LISTS = ("f_star", "f_star_sm", "cov_f", "cov_f_sm", "A", "Gamma", "C", "Sigma", "x_train", "y_train")
+
+    def __getstate__(self):
+        """Host copies of the state; caches, pending status words and the online pool's slot are dropped."""
+        d = {k: v for k, v in self.__dict__.items() if k not in ("_stk", "_pending", "_graph_keepalive", "_slot", "_dyn", "theta_source",
+                                                                  "_Lobs", "_def_diag_key", "_def_diag")}
+        cpu = lambda t: t.detach().cpu() if torch.is_tensor(t) else t           # noqa: E731
+        for name in self._TENSOR_LISTS:
+            d[name] = [cpu(t) for t in getattr(self, name)]
+        for name in ("A_def", "Gamma_def", "C_def", "Sigma_def", "ini_cov_def", "x_basis"):
+            d[name] = cpu(d.get(name))
+        for name in ("internal_params", "observation_params"):
+            m = d.get(name)
+            if m is not None:
+                d[name] = matrix_normal_inv_wishart(cpu(m.m_mean), cpu(m.m_r_cov), m.n0, cpu(m.scale))
+        d["theta_owner_fixed"] = getattr(self.theta_source, "fixed_theta", None)
+        return d
+
+    def __setstate__(self, d):
+        fixed = d.pop("theta_owner_fixed", None)
+        self.__dict__.update(d)
+        self._stk, self._pending, self._Lobs, self.theta_source = {}, [], None, None
+        if self.fixed_theta is None:
+            self.fixed_theta = fixed
+
+    def _set_device(self, dev):
+        """Move the (unpickled, host-resident) state to `dev`."""
+        mv = lambda t: t.to(dev) if torch.is_tensor(t) else t                   # noqa: E731
+        self.device = dev
+        self.gp.device = self.gp.kernel.device = dev
+        self.gp.x_basis = mv(self.gp.x_basis)
+        for name in self._TENSOR_LISTS:
+            setattr(self, name, [mv(t) for t in getattr(self, name)])
+        for name in ("A_def", "Gamma_def", "C_def", "Sigma_def", "ini_cov_def", "x_basis"):
+            setattr(self, name, mv(getattr(self, name)))
+        for name in ("internal_params", "observation_params"):
+            m = getattr(self, name)
+            if m is not None:
+                setattr(self, name, matrix_normal_inv_wishart(mv(m.m_mean), mv(m.m_r_cov), m.n0, mv(m.scale)))
+        self._stk = {}
+
     # ------------------------------------------------------------------ state (a12)
     def cond_to_torch(self, x):
         if x is None:

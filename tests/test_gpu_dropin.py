@@ -139,3 +139,32 @@ def test_unbuilt_options_say_so():
     sw_gp, x_trains, data = _driver(g)
     with pytest.raises(NotImplementedError):
         sw_gp.include_sample(x_trains[0], data[0], with_warp=True)
+
+
+def test_save_swgp_round_trip_and_kernel_objects(tmp_path):
+    """GPI_HDP.save_swgp (GPI_HDP.py:3946-3950: keep_last_all + pickle) and kernels= objects (GPI_HDP.py:160-168): a model saved after
+    a short include_batch and loaded again classifies new beats exactly as the model it was saved from; a scikit-learn kernel object
+    gives the same model as the keyword arguments it stands for."""
+    import hdpgpc.GPI_HDP as hdpgp
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, WhiteKernel
+    from offline_trace import build_model
+    g = golden("include_batch_r100_n80.npz")
+    y = np.asarray(g["y"], dtype=np.float64)
+    sw, x_trains, data = build_model(g, y[:60])
+    sw.include_batch(x_trains, data, with_warp=False)
+    path = str(tmp_path / "model.pkl")
+    sw.save_swgp(path)
+    sw2 = hdpgp.GPI_HDP.load_swgp(path)
+    assert sw2.M == sw.M and [len(m.indexes) for m in sw2.gpmodels[0]] == [len(m.indexes) for m in sw.gpmodels[0]]
+    xb = np.arange(float(y.shape[1]))[:, None]
+    new = y[60:80, :, None]
+    xs = np.array([xb] * new.shape[0])
+    la, lb = sw.cluster_new_batch(xs, new), sw2.cluster_new_batch(xs, new)
+    assert torch.equal(la.cpu(), lb.cpu())
+    # kernels= : the object the reference would have built from the keyword arguments
+    std, std_dif, bs0, bs1, bg0, bg1 = (float(v) for v in g["estimators"])
+    kern = ConstantKernel(300.0, (300.0, 1500.0)) * RBF(3.0, (1.0, 20.0)) + WhiteKernel(bs0, (bs0, bs1))
+    a = hdpgp.GPI_HDP(xb, n_outputs=1, kernels=[kern], ini_gamma=std_dif, ini_sigma=std, bound_gamma=(bg0, bg1), verbose=False)
+    b = hdpgp.GPI_HDP(xb, n_outputs=1, ini_lengthscale=3.0, ini_outputscale=300.0, bound_sigma=(bs0, bs1), ini_gamma=std_dif, ini_sigma=std,
+                      bound_gamma=(bg0, bg1), verbose=False)
+    assert a.gpmodels[0][0].gp.kernel.params() == b.gpmodels[0][0].gp.kernel.params() and a.bound_sigma_def == b.bound_sigma_def
