@@ -177,6 +177,8 @@ class GPI_HDP(OfflineLoop, OnlineLoop):
         g.gp.fitted = gpmodel.gp.fitted
         if getattr(gpmodel, "_def_diag_key", None) == (id(g.Sigma_def), id(g.Gamma_def)):     # same prior objects: same verdict
             g._def_diag_key, g._def_diag = gpmodel._def_diag_key, gpmodel._def_diag
+        if getattr(gpmodel, "_dyn_def", None) is not None:
+            g._dyn_def = gpmodel._dyn_def
         return g
 
     def keep_last_all(self):

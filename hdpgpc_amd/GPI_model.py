@@ -181,7 +181,7 @@ class GPI_model:
     def __getstate__(self):
         """Host copies of the state; caches, pending status words and the online pool's slot are dropped."""
         d = {k: v for k, v in self.__dict__.items() if k not in ("_stk", "_pending", "_graph_keepalive", "_slot", "_dyn", "theta_source",
-                                                                  "_Lobs", "_def_diag_key", "_def_diag")}
+                                                                  "_Lobs", "_def_diag_key", "_def_diag", "_dyn_def")}
         cpu = lambda t: t.detach().cpu() if torch.is_tensor(t) else t           # noqa: E731
         for name in self._TENSOR_LISTS:
             d[name] = [cpu(t) for t in getattr(self, name)]
@@ -774,7 +774,7 @@ class GPI_model:
         riding = T <= 128
         tt = T * T
         dev = self.device
-        new = lambda *shape: torch.zeros(shape, dtype=f64, device=dev)      # noqa: E731
+        new = ch.get("alloc") or (lambda *shape: torch.zeros(shape, dtype=f64, device=dev))      # noqa: E731  (a pool hands out slices of its arena)
         ws = ch["ws"]
         A, G, C, S, Psm, c0 = (ws[i * tt:(i + 1) * tt].view(T, T) for i in range(6))
         m0, Fsm = ws[6 * tt:6 * tt + T], ws[6 * tt + T:]
@@ -1214,6 +1214,13 @@ class GPI_model:
             ent = self._dyn = (key, bool(torch.any(G != 0)))
         return ent[1]
 
+    def _dyn_prior(self):
+        """bool(any(Gamma_def != 0)) (GPI_model.py:470), looked up once per prior object."""
+        ent = getattr(self, "_dyn_def", None)
+        if ent is None or ent[0] is not self.Gamma_def:
+            ent = self._dyn_def = (self.Gamma_def, bool(torch.any(self.Gamma_def != 0)))
+        return ent[1]
+
     # ------------------------------------------------------------------ a9
     def return_LDS_param_likelihood(self, first=False):
         """GPI_model.py:459-486."""
@@ -1224,7 +1231,7 @@ class GPI_model:
             Gam_ = Gam_ + 2.0 * torch.mean(torch.diagonal(Gam_)) * eye
             Sig_ = Sig_ + 2.0 * torch.mean(torch.diagonal(Sig_)) * eye
         Ms, Ss, means, scales = [C_], [Sig_], [self.C_def], [self.Sigma_def]
-        if bool(torch.any(self.Gamma_def != 0)):
+        if self._dyn_prior():
             Ms.append(A_), Ss.append(Gam_), means.append(self.A_def), scales.append(self.Gamma_def)
         # the prior scales are the initial sigma I / gamma I unless a caller replaced them: checked once per pair of objects
         key = (id(self.Sigma_def), id(self.Gamma_def))

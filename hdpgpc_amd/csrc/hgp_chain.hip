@@ -155,6 +155,79 @@ void launch_inv_rhs(const InvRhsArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_wave_inv_rhs<NB>, dim3((waves + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, st, a);
 }
 
+// The same job for SMALL batches (the member step of a few chains: 4 or 2 matrices per chain), where the launch is one exposed
+// latency and a wave that factors the whole matrix by itself is the whole of it (31 us at T = 90: six serial diag16 plus ~280
+// dependent MFMAs on one SIMD).  Here a WORKGROUP of four waves takes each (matrix, panel): the tiles are dealt over the waves
+// (Coop<NB>), only the pivot chain stays serial.  NB is padded to a multiple of four (identity blocks); the padded steps are not
+// taken (kstop).  Arithmetic per tile is that of wave_factor (same operations in the same order): results identical bit for bit.
+template <int NB>
+__global__ __launch_bounds__(64 * WAVES) void k_coop_inv_rhs(InvRhsArgs a) {
+  using C = Coop<NB>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* rowbuf = smem;
+  double* Rbuf = rowbuf + NB * 256;
+  double* Wbuf = Rbuf + NB * 256;
+  double* scr = Wbuf + 256;
+  double* red = scr + DIAG_SCR;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int T = a.T, nblk = (T + 15) >> 4;
+  const int m = blockIdx.x, Jq = blockIdx.y;            // gridDim.y = 2 nblk: panels of L^-1, then panels of L^-1 op(B)
+  const bool is_rhs = Jq >= nblk;
+  const int Jc = is_rhs ? Jq - nblk : Jq;
+  const bool skip = (is_rhs && (!a.rhs || (a.rhs_on && a.rhs_on[m] == 0))) || (!is_rhs && !a.Linv);
+  if (skip) {
+    if (Jq == 0 && !a.Linv && threadIdx.x == 0 && a.info && (!a.rhs || (a.rhs_on && a.rhs_on[m] == 0))) a.info[m] = 0;
+    return;
+  }
+  const double* A = a.A + (size_t)m * T * T;
+  d4 U[C::NT];
+  coop_load_sym_upper<NB>(U, A, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
+  __syncthreads();   // rowbuf served as per-wave staging for the loader
+  {
+    double sh = a.add;
+    if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(coop_diag_abs_mean<NB>(U, T, wave, lane, a.add, red), F64_EPS);
+    if (sh != 0.0) coop_add_diag<NB>(U, sh, T, wave, lane);
+  }
+  const double* B = is_rhs ? a.rhs + (size_t)m * T * T : nullptr;
+  for (int K = wave; K < NB; K += WAVES) {
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * K + g + 4 * r, j = 16 * Jc + c;
+      if (!is_rhs) v[r] = (K == Jc && g + 4 * r == c) ? 1.0 : 0.0;
+      else v[r] = (i < T && j < T) ? (a.rhs_trans ? B[(size_t)j * T + i] : B[(size_t)i * T + j]) : 0.0;
+    }
+    lds_tile_store(Rbuf, K, lane, v);
+  }
+  __syncthreads();
+  PivotAcc pa;
+  pa.init();
+  coop_factor<NB, true>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T, nullptr, nullptr, 0, nullptr, nullptr, nblk);
+  double* Z = (is_rhs ? a.rhs_out : a.Linv) + (size_t)m * T * T;
+  for (int K = wave; K < nblk; K += WAVES) {
+    const d4 z = lds_tile_load(Rbuf, K, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * K + g + 4 * r, j = 16 * Jc + c;
+      if (i < T && j < T) Z[(size_t)i * T + j] = (is_rhs || K >= Jc) ? z[r] : 0.0;
+    }
+  }
+  if (Jq == (a.Linv ? 0 : nblk) && a.info) {   // the first panel sees every pivot
+    int info;
+    (void)coop_logdet_info(pa, wave, lane, red, reinterpret_cast<int*>(red + 8), info);
+    if (threadIdx.x == 0) a.info[m] = info;
+  }
+}
+
+template <int NB>
+int launch_coop_inv_rhs(const InvRhsArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_inv_rhs<NB>), lds)) return rc_;
+  hipLaunchKernelGGL(k_coop_inv_rhs<NB>, dim3(a.b, 2 * ((a.T + 15) >> 4)), dim3(64 * WAVES), lds, st, a);
+  return launch_status();
+}
+
 // -------------------------------------------------------------------------------------------- fused glue of the step
 // gather (rows `pos` of the stacks -> workspace, the member's observation) + the jittered right covariances of the two MNIW
 // updates  R' = R + 1e-2 max(mean |diag scale|, eps) I  (GPI_model.py:1312-1316), one launch.
@@ -349,6 +422,12 @@ int hgp_chol_inverse_rhs_batched_f64(const double* A, int T, int b, double jitte
   if (T > HGP_MAX_T_WAVE) return -2;
   InvRhsArgs a{A, T, b, jitter_rel, add_diag, Linv, rhs, rhs_on, rhs_trans, rhs_out, info};
   hipStream_t st = (hipStream_t)stream;
+  // few matrices (the member step of a few chains): one workgroup per (matrix, panel) - latency; many: one wave each - throughput
+  // (tools/time_inv_rhs.py, per call: T = 128 51 -> 31 us, T = 90 30 -> 27 us, T = 50 16.5 -> 13 us while the workgroups fit the
+  // chip in one round - one per CU at T > 64; beyond that the one-wave kernel wins.  HGP_INV_COOP_MAX_WG overrides, 0 = never.)
+  static const int coop_max_wg = getenv("HGP_INV_COOP_MAX_WG") ? atoi(getenv("HGP_INV_COOP_MAX_WG")) : 256;
+  if (T > 16 && (long)b * 2 * ((T + 15) >> 4) <= coop_max_wg)
+    return T <= 64 ? launch_coop_inv_rhs<4>(a, st) : launch_coop_inv_rhs<8>(a, st);
   switch (nb_for(T)) {
     case 2: launch_inv_rhs<2>(a, st); break;
     case 4: launch_inv_rhs<4>(a, st); break;

@@ -517,12 +517,17 @@ __device__ __forceinline__ d4 diag16_col(const d4& X, double* scr, int lane, Piv
 // of the symmetric Schur complement never reach a live entry).  ~470 instructions per block, dependency chain ~80 cycles per pivot.
 // Same interface as the other forms; results agree to rounding (multipliers S/p instead of (S/sqrt p)(S/sqrt p)).
 // ---------------------------------------------------------------------------------------------
+#ifndef HGP_DIAG_ROWCOPY
+#define HGP_DIAG_ROWCOPY 1   // 1 (shipped since round 4) = the three row copies of a pivot step through LDS memory: one ds_write2_b64, one
+                             // ds_read2_b64, one ds_read_b64 in the wave's scratch; 0 = six ds_bpermute_b32 (crossbar, no memory; round 3).
+                             // tools/probe_diag16: 2 811 vs 3 088 cycles per block; in the kernels (tools/ab_rowcopy.sh) k_pairs<8> 1.004 ->
+                             // 0.991 ms, k_pairs<6> 0.642 -> 0.616, cooph<16> 13.60 -> 13.37; results identical bit for bit
+#endif
 #ifndef HGP_DIAG_SCHED
-#define HGP_DIAG_SCHED 0     // 0 = the compiler's schedule (shipped); 2 = scheduling barriers keep the off-chain FMAs behind the next pivot's
-                             // broadcasts; 1 / 3 = fully pinned orders.  Round 4 measured all four (tools/probe_diag16, tools/ab_sched.sh,
-                             // profiles/r04_ab_sched.txt): 3 088 / 3 004 / 3 144 / 3 388 cycles per block in isolation, and NO difference
-                             // inside the kernels (k_pairs<8> 1.000-1.023 ms in every variant): the block is bound by its ~25
-                             // instructions per pivot, not by where they sit
+#define HGP_DIAG_SCHED 0     // 0 = the compiler's schedule; 4 = the pinned order below.  (Three other pinned orders, built on the ds_bpermute
+                             // form in round 4 - off-chain FMAs behind the broadcasts / crossbar instructions in one run / dealt two by
+                             // two into the reciprocal's gaps - measured 3 004 / 3 144 / 3 388 cycles per block against 3 088 and made no
+                             // difference inside the kernels: profiles/r04_ab_sched.txt; their code is gone.)
 #endif
 template <int G0>
 __device__ __forceinline__ double row_to_all(double v) {   // row G0 (16 lanes) of v copied to all four rows of the wave
@@ -574,8 +579,29 @@ __device__ __forceinline__ void elim_rest(double (&S)[4], double (&Z)[4], double
 #undef HGP_FD
 }
 
+// elim_rest one instruction at a time (I = 0 .. 5: S[RS+1], Z[RS+1], S[RS+2], Z[RS+2], ...; nothing beyond register 3), so that a
+// pinned order can place each where the pivot chain waits.  No s_nop: the DPP source (mrot) comes from an LDS read, never from
+// the VALU instruction in front (tools/check_dpp_hazard.py looks at the compiled stream).
+template <int RS, int I>
+__device__ __forceinline__ void rest_one(double (&S)[4], double (&Z)[4], double mrot, double nt, double ntz) {
+  constexpr int reg = RS + 1 + I / 2;
+  if constexpr (reg <= 3) {
+    if constexpr (I % 2 == 0)
+      asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(S[reg]) : "v"(mrot), "v"(nt), "n"(4 * reg));
+    else
+      asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(Z[reg]) : "v"(mrot), "v"(ntz), "n"(4 * reg));
+  }
+}
+
+struct NoBg {
+  template <class KC>
+  __device__ __forceinline__ void operator()(KC) const {}
+};
+// bg(integral_constant<int, k>), k = 0 .. 14: work of the CALLER that does not depend on this block (wave_factor hands in the
+// trailing-update MFMAs of the previous block step), issued once per pivot step where the pivot chain waits for its LDS round trip.
+template <class BG = NoBg>
 __device__ __forceinline__ d4 diag16_acc(const d4& X, double* scr, int lane, PivotAcc& pa, int col0,
-                                         double* Lout, int ldl, int nvalid) {
+                                         double* Lout, int ldl, int nvalid, BG&& bg = BG{}) {
   const int g = lane >> 4, c = lane & 15;
 #ifdef HGP_EXP_NODIAG   // in-situ knock-out experiment (diagnostic builds only)
   {
@@ -603,53 +629,68 @@ __device__ __forceinline__ d4 diag16_acc(const d4& X, double* scr, int lane, Piv
   const int crot = (c + g) & 15;
   double p = lane_bcast(S[0], 0);
   double sk = row_to_all_bperm(S[0], 4 * c), mrot = row_to_all_bperm(S[0], 4 * crot), zk = row_to_all_bperm(Z[0], 4 * c);
-#if HGP_DIAG_SCHED
-  // Round 4: the step's instruction ORDER is pinned.  A wave issues in order, so where the machine scheduler put things decided the
-  // step: (a) it moved the off-chain FMAs (elim_rest, an opaque asm block) in front of the next pivot's v_readlane and the six
-  // ds_bpermute - ~50 cycles back on the pivot chain; (b) with that fixed, the six crossbar instructions (~10 cycles of issue each)
-  // still sat in one run in front of the reciprocal.  Here the pivot is read first, and the crossbar instructions are dealt into
-  // the latency gaps of the reciprocal's dependent chain (v_rcp 21 cycles, each dependent f64 operation ~9.5: measured in
-  // tools/probe_lat.hip), two per gap, in the order their results are needed (s_k, z_k, then the rotated copy for the FMAs).
+#if HGP_DIAG_SCHED == 4
+  // The step's instruction ORDER is pinned (a wave issues in order; every statement below is fenced by a scheduling barrier):
+  // behind the two FMAs that finish row k + 1 come its LDS copy and the pivot read, then v_rcp_f64 at once, and the off-chain FMAs of
+  // step k (one instruction each, rest_one) are dealt into the latency gaps of the reciprocal's dependent chain (v_rcp 21 cycles,
+  // each dependent f64 operation ~9.5, tools/probe_lat.hip) instead of sitting in one run in front of it.
+#define HGP_SB __builtin_amdgcn_sched_barrier(0)
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(0));
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(0));
   double rp = rcp_nr(p);
   static_for<0, 15>([&](auto kc) {
     constexpr int k = decltype(kc)::value, r0 = k >> 2, g0 = k & 3;
     constexpr int RS = (g0 == 3) ? r0 + 1 : r0;                          // register of row k + 1
     constexpr int RMF = (g0 == 3) ? 0xf : (0xf << (g0 + 1)) & 0xf;      // its rows below the pivot
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(k));
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(k));
     if (Lout != nullptr) Us[r0] = (g == g0) ? sk : Us[r0];
     const double nt = -(sk * rp), ntz = -(zk * rp), mr = mrot;
+    HGP_SB;
     elim_crit<RS, RMF>(S, Z, mr, nt, ntz);
-    __builtin_amdgcn_sched_barrier(0);
+    HGP_SB;
     constexpr int k1 = k + 1, g1 = k1 & 3;
-    p = lane_bcast(S[RS], 16 * g1 + k1);
     if constexpr (k1 < 15) {
-      const double y = __builtin_amdgcn_rcp(p);
-      sk = row_to_all_bperm(S[RS], 4 * (16 * g1 + c));
-      const double e = fma(-p, y, 1.0);
-      zk = row_to_all_bperm(Z[RS], 4 * (16 * g1 + c));
-      const double ye = y * e;
-      mrot = row_to_all_bperm(S[RS], 4 * (16 * g1 + crot));
-      rp = fma(ye, e, y + ye);
-#if HGP_DIAG_SCHED == 1      // 2 v_readlane + v_rcp | 6 DS | the reciprocal's dependent operations
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x080, 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-#elif HGP_DIAG_SCHED == 3    // the crossbar instructions dealt into the gaps of the reciprocal's chain, two per gap
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-#endif                       // 2: only the two scheduling barriers around the block (the compiler orders the inside)
+      scr[lane] = S[RS];
+      scr[64 + lane] = Z[RS];
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_sched_barrier(0);
-    elim_rest<RS>(S, Z, mr, nt, ntz);
+    p = lane_bcast(S[RS], 16 * g1 + k1);
+    HGP_SB;
+    if constexpr (k1 < 15) {
+      sk = scr[16 * g1 + c];
+      zk = scr[64 + 16 * g1 + c];
+      mrot = scr[16 * g1 + crot];
+      __builtin_amdgcn_wave_barrier();
+      HGP_SB;
+      const double y = __builtin_amdgcn_rcp(p);
+      HGP_SB;
+      bg(kc);
+      HGP_SB;
+      rest_one<RS, 0>(S, Z, mr, nt, ntz);
+      rest_one<RS, 1>(S, Z, mr, nt, ntz);
+      HGP_SB;
+      const double e = fma(-p, y, 1.0);
+      HGP_SB;
+      rest_one<RS, 2>(S, Z, mr, nt, ntz);
+      HGP_SB;
+      const double ye = y * e, t = fma(y, e, y);
+      HGP_SB;
+      rest_one<RS, 3>(S, Z, mr, nt, ntz);
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(k1));
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(k1));
+      HGP_SB;
+      rp = fma(ye, e, t);
+      HGP_SB;
+      rest_one<RS, 4>(S, Z, mr, nt, ntz);
+      rest_one<RS, 5>(S, Z, mr, nt, ntz);
+      HGP_SB;
+    } else {
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(k1));
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(k1));
+      bg(kc);
+      elim_rest<RS>(S, Z, mr, nt, ntz);
+    }
   });
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(15));
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(pvhi) : "s"(__double2hiint(p)), "n"(15));
+#undef HGP_SB
 #else
   static_for<0, 15>([&](auto kc) {
     constexpr int k = decltype(kc)::value, r0 = k >> 2, g0 = k & 3;
@@ -664,10 +705,23 @@ __device__ __forceinline__ d4 diag16_acc(const d4& X, double* scr, int lane, Piv
     constexpr int k1 = k + 1, g1 = k1 & 3;
     p = lane_bcast(S[RS], 16 * g1 + k1);
     if constexpr (k1 < 15) {
+#if HGP_DIAG_ROWCOPY == 1
+      // the row copies through LDS memory instead of the crossbar: one ds_write2_b64 + one ds_read2_b64 + one ds_read_b64 (64-bit)
+      // in place of six ds_bpermute_b32 - three instructions fewer per pivot, at 77 instead of ~25 cycles of latency
+      scr[lane] = S[RS];
+      scr[64 + lane] = Z[RS];
+      __builtin_amdgcn_wave_barrier();
+      sk = scr[16 * g1 + c];
+      zk = scr[64 + 16 * g1 + c];
+      mrot = scr[16 * g1 + crot];
+      __builtin_amdgcn_wave_barrier();
+#else
       sk = row_to_all_bperm(S[RS], 4 * (16 * g1 + c));
       mrot = row_to_all_bperm(S[RS], 4 * (16 * g1 + crot));
       zk = row_to_all_bperm(Z[RS], 4 * (16 * g1 + c));
+#endif
     }
+    bg(kc);
     elim_rest<RS>(S, Z, mr, nt, ntz);
   });
   asm("v_writelane_b32 %0, %1, %2" : "+v"(pvlo) : "s"(__double2loint(p)), "n"(15));
@@ -716,11 +770,11 @@ __device__ __forceinline__ d4 diag16_acc(const d4& X, double* scr, int lane, Piv
 #define HGP_DIAG_IMPL 3   // 3 = diag16_acc everywhere (shipped: k_pairs<8> 1.265 -> 1.121 ms, k_pairs<6> 0.757 -> 0.677, k_pairs_cooph<16> 7.39 -> 6.91 per 16 384 pairs);
                           // 0 = rounds 1-2 (diag16_valu / MFMA-blocked diag16); 1 / 2 = diag16_col (measured SLOWER in the kernels: see diag16_col); 4 = diag16_acc for the VALU users only
 #endif
-template <bool VALU>
+template <bool VALU, class BG = NoBg>
 __device__ __forceinline__ d4 diag16_sel(const d4& X, double* scr, int lane, PivotAcc& pa, int col0, double* Lout, int ldl,
-                                         int nvalid) {
+                                         int nvalid, BG&& bg = BG{}) {
 #if HGP_DIAG_IMPL == 3
-  return diag16_acc(X, scr, lane, pa, col0, Lout, ldl, nvalid);
+  return diag16_acc(X, scr, lane, pa, col0, Lout, ldl, nvalid, bg);
 #elif HGP_DIAG_IMPL == 4
   return VALU ? diag16_acc(X, scr, lane, pa, col0, Lout, ldl, nvalid) : diag16(X, scr, lane, pa, col0, Lout, ldl, nvalid);
 #elif HGP_DIAG_IMPL == 2
@@ -743,7 +797,27 @@ __device__ __forceinline__ d4 diag16_sel(const d4& X, double* scr, int lane, Piv
 // RHSMODE: 0 = none; 1 = one block column of 16 right-hand sides as MFMA tiles R[K]; 2 = ONE right-hand side kept
 // as a vector in LDS (dvec[16 NB], per wave) and eliminated on the VALU next to the MFMA stream: on exit dvec
 // holds z = L^{-1} d and the return value is z^T z (valid in every lane).
-template <int NB, int RHSMODE, bool DIAG_VALU = false, bool RHS_DEFER = false>
+#ifndef HGP_LOOKAHEAD
+#define HGP_LOOKAHEAD 1   // shipped since round 4 (tools/ab_look.sh: k_pairs<8> 0.998 -> 0.980 ms, k_pairs<6> 0.625 -> 0.612; bit-identical results); 0 = trailing update in one run
+#endif
+// The trailing-update MFMAs of block step Kp that wave_factor hands to diag16_acc of block Kp + 1 (look-ahead): every tile
+// (I, J), Kp < I <= J < NB, except (Kp + 1, Kp + 1) itself, which the next diagonal block needs first.  Operation q of the 4 NT:
+// k-step q / NT of tile q % NT (consecutive operations go to different accumulators); tiles in row-major order.
+template <int NB, int Kp>
+struct Pending {
+  static constexpr int M = NB - 1 - Kp, NT = M * (M + 1) / 2 - 1, N = 4 * NT, CH = (N + 14) / 15;
+  static constexpr int row(int t) {
+    int u = t + 1, I = Kp + 1;                 // u: index among all tiles of the trailing matrix, (Kp+1, Kp+1) being 0
+    while (u >= NB - I) { u -= NB - I; ++I; }
+    return I;
+  }
+  static constexpr int col(int t) {
+    int u = t + 1, I = Kp + 1;
+    while (u >= NB - I) { u -= NB - I; ++I; }
+    return I + u;
+  }
+};
+template <int NB, int RHSMODE, bool DIAG_VALU = false, bool RHS_DEFER = false, bool LOOK = (HGP_LOOKAHEAD != 0)>
 __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R)[NB], double* scr, double* Wlds,
                                               double* dvec, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n) {
   constexpr bool RHS = (RHSMODE == 1);
@@ -754,12 +828,26 @@ __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R
   double dp[NB];
 #pragma unroll
   for (int K = 0; K < NB; ++K) dp[K] = 0.0;
-#pragma unroll
-  for (int K = 0; K < NB; ++K) {
+  static_for<0, NB>([&](auto Kc) {
+    constexpr int K = decltype(Kc)::value;
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;
     double* Ld = (Lout != nullptr) ? Lout + (size_t)(16 * K) * ldl + 16 * K : nullptr;
-    const d4 W = diag16_sel<DIAG_VALU>(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
+    d4 W;
+    if constexpr (LOOK && K > 0 && K + 1 < NB) {
+      // look-ahead: the pivot chain of the diagonal block leaves the f64 pipe idle while it waits for its LDS round trips
+      // (~130 of ~165 cycles per pivot); the trailing-update MFMAs of step K - 1 that this block does not depend on fill it
+      using P = Pending<NB, K - 1>;
+      W = diag16_sel<DIAG_VALU>(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K, [&](auto kc) {
+        constexpr int k = decltype(kc)::value, q0 = k * P::CH, q1 = (q0 + P::CH < P::N) ? q0 + P::CH : P::N;
+        static_for<q0, q1>([&](auto qc) {
+          constexpr int q = decltype(qc)::value, s = q / P::NT, t = q % P::NT, I = P::row(t), J = P::col(t);
+          U[tix(I, J, NB)] = mfma_sub(U[tix(K - 1, I, NB)][s], U[tix(K - 1, J, NB)][s], U[tix(I, J, NB)]);
+        });
+      });
+    } else {
+      W = diag16_sel<DIAG_VALU>(U[tix(K, K, NB)], scr, lane, pa, 16 * K, Ld, ldl, n - 16 * K);
+    }
     if (Wlds != nullptr) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) Wlds[(K * 4 + s) * 64 + lane] = W[s];
@@ -833,17 +921,20 @@ __device__ __forceinline__ double wave_factor(d4 (&U)[NB * (NB + 1) / 2], d4 (&R
     // trailing update: A_IJ -= U_KI^T U_KJ  for K < I <= J  (and the rhs tiles I > K).  No look-ahead: on gfx950 the
     // f64 MFMA and f64 VALU share the DP pipe (tools/probe_coexec.hip: 1 MFMA + 12 independent v_fma_f64 = 64 + 64 clk),
     // so deferring these MFMAs into the VALU stream of the next diagonal block gains nothing (tried, measured).
+    // With LOOK only the next diagonal tile (and the rhs tiles) are updated here; the rest rides in the next diag16_acc (above).
 #pragma unroll
     for (int I = K + 1; I < NB; ++I) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int J = I; J < NB; ++J)
+        for (int J = I; J < NB; ++J) {
+          if (LOOK && K + 2 < NB && !(I == K + 1 && J == K + 1)) continue;
           U[tix(I, J, NB)] = mfma_sub(U[tix(K, I, NB)][s], U[tix(K, J, NB)][s], U[tix(I, J, NB)]);
+        }
         if (RHS) R[I] = mfma_sub(U[tix(K, I, NB)][s], R[K][s], R[I]);
       }
     }
-  }
+  });
   return (RHSMODE == 2) ? wave_sum(zq) : 0.0;
 }
 
@@ -1171,12 +1262,14 @@ template <int NB, int RHSMODE>
 __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* rowbuf, double* Rbuf, double* Wbuf, double* scr,
                                               int wave, int lane_in, PivotAcc& pa, double* Lout, int ldl, int n,
                                               double* dvec = nullptr, double* Wout = nullptr, int ldw = 0,
-                                              double* Lpack = nullptr, double* Wpack = nullptr) {
+                                              double* Lpack = nullptr, double* Wpack = nullptr, int kstop = NB) {
   // Lpack / Wpack (optional): the factor in MFMA OPERAND order for a consumer that streams it (hgp_matlik_coop.hip) - the
   // accumulator tile of U_KJ (K < J) IS the A operand of L[J, K] = U_KJ^T, so it is stored as it stands, 32 bytes per lane, at
   // tile index J (J - 1) / 2 + K; the inverses W_K of the diagonal blocks (A-operand order already) at tile index K of Wpack.
   // Wout (optional): the inverses W_K = L_KK^{-1} of the diagonal blocks go to the diagonal blocks of this [n, ldw] matrix -
   // they ARE the diagonal blocks of L^{-1}; k_trtri (hgp_kernels.hip) fills in the rest from L.
+  // kstop (optional, the same in every thread): block steps K >= kstop are not taken - for callers whose blocks from kstop on are
+  // identity padding (their factor is the identity, nothing of it is read) and who only want the right-hand side / the pivots.
   using C = Coop<NB>;
   constexpr bool RHS = (RHSMODE == 1);
   double zq = 0.0;
@@ -1188,8 +1281,7 @@ __device__ __forceinline__ double coop_factor(d4 (&U)[Coop<NB>::NT], double* row
 #endif
 #pragma unroll
   for (int K = 0; K < NB; ++K) {
-    constexpr int dummy = 0;
-    (void)dummy;
+    if (K >= kstop) break;
     const int qK = K / 4, wK = C::owner(K);
     const int lane = launder(lane_in);
     const int g = lane >> 4, c = lane & 15;

@@ -108,6 +108,10 @@ class OnlinePool:
         self.badc_all = torch.zeros((cap, 2), dtype=torch.int32, device=dev)     # candidate steps (cleared per beat)
         self.sync_all = torch.zeros(cap, dtype=torch.int32, device=dev)
         self.est_mean, self.mean_last = new(cap, T), new(cap, T)
+        # the step buffers of every slot (GPI_model._chain_lists: 21 T x T matrices and 6 vectors) come out of ONE arena, zeroed once:
+        # adopting a cluster used to cost 43 allocations and 22 MB of memsets at T = 256
+        self.ARENA = 21 * T * T + 6 * T + 128          # (every piece starts on a 32-byte boundary)
+        self.arena = new(cap, self.ARENA)
         self.ini_noise_all = new(cap)
         self.lists = _LevelLists(cap, dev)
         self.descs_dirty = True
@@ -139,7 +143,18 @@ class OnlinePool:
         ch["ws"] = self.ws_all[c]
         ch["bad"], ch["sync"] = self.bad_all[c], self.sync_all[c:c + 1]
         ch["Y"], ch["y_row0"] = self.ybuf, -1
+        arena, used = self.arena[c], [0]
+        arena.zero_()
+
+        def alloc(*shape):
+            n = int(np.prod(shape))
+            out = arena[used[0]:used[0] + n].view(*shape)
+            used[0] += (n + 3) & ~3
+            return out
+
+        ch["alloc"] = alloc
         sl.g._chain_lists(ch, views=self._views(c))
+        del ch["alloc"]
         T, tt = self.T, self.T * self.T
         Cw = ch["ws"][2 * tt:3 * tt].view(T, T)
         ch["lv"][6].add(Cw, ch["bufs"]["f_post"], self.est_mean[c])          # C_last f_post: the mean estimate_new scores against
@@ -159,7 +174,7 @@ class OnlinePool:
     def supports(g):
         """The chain step covers: dynamic model, no estimation limit, at least one member, last filtered = last smoothed state
         (always true for a chain grown online), no tracked rank-1 factor."""
-        if g.N < 1 or g.estimation_limit != np.inf or g._rank1_on() or not g._is_dynamic():
+        if g.N < 1 or g.estimation_limit != np.inf or g._rank1_on() or not g._is_dynamic() or not g._dyn_prior():
             return False
         n = len(g.f_star)
         if not (n == len(g.f_star_sm) == len(g.cov_f) == len(g.cov_f_sm) == len(g.A) == len(g.Gamma) == len(g.C) == len(g.Sigma)):
@@ -315,13 +330,18 @@ class OnlinePool:
         return -0.5 * quad - 0.5 * T * LOG2PI, info
 
     # ------------------------------------------------------------------ candidates
-    def candidates(self, t_new, q_lat_cols, indexes):
+    def candidates(self, t_new, q_lat_cols, indexes, extra=None):
         """Every cluster with the beat of begin_beat(y) added (dry run).  q_lat_cols [T_all, M']: the clusters' current latent-transition
         columns in SLOT order; indexes[c] = member segment ids of slot c.  Returns
         (est [M] device: estimate_new's score, cols [T_all, M] device: the candidates' latent-transition columns,
-         lds [M] host floats: return_LDS_param_likelihood of the candidates)."""
+         lds [M] host floats: return_LDS_param_likelihood of the candidates).
+        extra (optional): the would-be NEW cluster (one member, GPI_HDP.py:1990-1996) - its single latent-transition score and its two
+        parameter likelihoods ride the same batched a8 / a9 calls; two more return values then: (its a8 score - device scalar, its
+        return_LDS_param_likelihood - host float)."""
         M, T = len(self.slots), self.T
         tt = T * T
+        if extra is not None and (M >= self.cap or extra.N != 1 or not extra._dyn_prior()):
+            extra = None                                        # no room behind the last slot (or not the plain case): the caller's job
         self.badc_all[:M].zero_()
         self._step(0, M, dry=True, gather=False)               # begin_beat(y) of this beat gathered the state
         # estimate_new: the beat against (C_last f_post, Sigma_last), `first` inflation for one-member clusters
@@ -358,22 +378,44 @@ class OnlinePool:
         # a9: (C, Sigma) and (A, Gamma) of the NEW row against their priors
         put(row(iC, N + 1, tt), self.MN_M, 0, tt), put(row(iS, N + 1, tt), self.MN_S, 0, tt)
         put(row(iA, N + 1, tt), self.MN_M, 1, tt), put(row(iG, N + 1, tt), self.MN_S, 1, tt)
+        nl, nm = 3 * M, 2 * M
+        diag = all(sl.def_diag for sl in self.slots)
+        if extra is not None:   # one a8 item (member 0 of a one-member cluster: GPI_model._lat_indices) and two a9 items behind the slots'
+            e = extra
+            fs, cs = e.f_star_sm[1].contiguous(), e.cov_f_sm[1].contiguous()
+            Ae, Ge, Ce, Se = (m_.contiguous() for m_ in (e.A[-1], e.Gamma[-1], e.C[-1], e.Sigma[-1]))
+            defs = [m_.contiguous() for m_ in (e.C_def, e.Sigma_def, e.A_def, e.Gamma_def)]
+            self._extra_keep = (fs, cs, Ae, Ge, Ce, Se, defs)
+            one_ = lambda t, buf, j, n: (src.append(np.array([t.data_ptr()], dtype=np.int64)),                       # noqa: E731
+                                         dst.append(np.array([buf.data_ptr() + j * 8 * n], dtype=np.int64)), cnt.append(np.array([n], dtype=np.int64)))
+            one_(fs, self.LF_cur, nl, T), one_(fs, self.LF_prev, nl, T), one_(Ae, self.LA, nl, tt), one_(Ge, self.LG, nl, tt), one_(cs, self.LC, nl, tt)
+            one_(Ce, self.MN_M, nm, tt), one_(Se, self.MN_S, nm, tt), one_(Ae, self.MN_M, nm + 1, tt), one_(Ge, self.MN_S, nm + 1, tt)
+            one_(defs[0], self.MN_mean, nm, tt), one_(defs[1], self.MN_scale, nm, tt)
+            one_(defs[2], self.MN_mean, nm + 1, tt), one_(defs[3], self.MN_scale, nm + 1, tt)
+            nl, nm = nl + 1, nm + 2
+            if getattr(e, "_def_diag_key", None) == (id(e.Sigma_def), id(e.Gamma_def)):
+                diag = diag and e._def_diag
+            else:
+                diag = diag and all(bool(torch.equal(s_, torch.diag(torch.diagonal(s_)))) for s_ in (e.Sigma_def, e.Gamma_def))
         table = np.stack([np.concatenate(src), np.concatenate(dst), np.concatenate(cnt)], axis=1)
         tdev = ops.to_dev(table, torch.int64, self.device)
         ops.copy_list(tdev, table.shape[0], tt)
-        lat, info_l = ops.lat_error(self.LF_cur[:3 * M], self.LF_prev[:3 * M], self.LA[:3 * M], self.LG[:3 * M], self.LC[:3 * M])
+        lat, info_l = ops.lat_error(self.LF_cur[:nl], self.LF_prev[:nl], self.LA[:nl], self.LG[:nl], self.LC[:nl])
         lat = lat - 0.5 * T * LOG2PI
-        mn, info_m = ops.mniw_loglik(self.MN_M[:2 * M], self.MN_S[:2 * M], self.MN_mean[:2 * M], None, self.MN_scale[:2 * M],
-                                     scale_is_diagonal=all(sl.def_diag for sl in self.slots))
-        lds_dev = torch.sum(mn.view(M, 2), dim=1) / T * 100.0
+        if diag:
+            mn, info_m = ops.mniw_loglik(self.MN_M[:nm], self.MN_S[:nm], self.MN_mean[:nm], None, self.MN_scale[:nm], scale_is_diagonal=True)
+        else:
+            mn, info_m = ops.mniw_loglik(self.MN_M[:nm], self.MN_S[:nm], self.MN_mean[:nm], None, self.MN_scale[:nm], scale_is_diagonal=False)
+        lds_dev = torch.sum(mn.view(nm // 2, 2), dim=1) / T * 100.0
         # one host round trip for everything the loop branches on
         flat = torch.cat([lds_dev, info.to(f64), info_l.to(f64), info_m.to(f64), self.badc_all[:M].reshape(-1).to(f64)]).cpu().numpy()
+        nx = nm // 2
         lds = flat[:M]
-        if flat[M:7 * M].any():                   # score [M] / a8 [3 M] / a9 [2 M] infos
-            bad = int(np.nonzero(flat[M:7 * M])[0][0])
-            what = "log_sq_error" if bad < M else ("log_lat_error" if bad < 4 * M else "log_likelihood_MNIW")
+        if flat[nx:nx + M + nl + nm].any():       # score [M] / a8 [nl] / a9 [nm] infos
+            bad = int(np.nonzero(flat[nx:nx + M + nl + nm])[0][0])
+            what = "log_sq_error" if bad < M else ("log_lat_error" if bad < M + nl else "log_likelihood_MNIW")
             raise torch.linalg.LinAlgError(f"{what}: the input is not positive-definite (online candidate step)")
-        badc = flat[7 * M:].reshape(M, 2)
+        badc = flat[nx + M + nl + nm:].reshape(M, 2)
         if badc[:, 1].any():
             raise torch.linalg.LinAlgError("posterior / backwards_pair: the input is not positive-definite (online candidate step)")
         # the candidates' columns: the cluster's own column with (up to) three entries replaced
@@ -389,6 +431,8 @@ class OnlinePool:
         dev = self.device
         ix = ops.to_dev(np.array([rr, cc, vv]), torch.int64, dev)
         cols[ix[0], ix[1]] = lat[ix[2]]
+        if extra is not None:
+            return est, cols, lds, lat[3 * M], float(flat[M])
         return est, cols, lds
 
     # ------------------------------------------------------------------ commit

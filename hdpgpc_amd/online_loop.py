@@ -236,29 +236,34 @@ class OnlineLoop:
             prov.reinit_LDS(save_last=False)
             prov._defer_checks = True                                # its LAPACK statuses are read together, below
             q_prev[-1, -1, ld] = prov.estimate_new_and_include(t, x, y[:, [ld]]) + liks[-1]
-            q_lat_prev[:, -1, ld] = prov.compute_q_lat_all(n_hist, h_ini=1.0)
-            host = torch.stack([torch.argmax(q_prev[-1]).to(f64), prov.return_LDS_param_likelihood()]).cpu()   # one round trip
+            birth_best = int(torch.argmax(q_prev[-1])) == M          # the new cluster scores the beat best: is it worth it?
+            order = q_ord.tolist() if birth_best else []
+            lds_cur = [g.lds_param_likelihood_value() for g in self.gpmodels[ld]]
+            lds_cand = lds_prov = None
+            if order:
+                if pool is not None:
+                    # the new cluster's own latent-transition score and parameter likelihoods ride the candidates' batched calls
+                    m_of = np.argsort(slot_of)                         # cluster index of every slot
+                    res = pool.candidates(t, q_lat[:, ops.to_dev(m_of, torch.int64, dev), ld].contiguous(), [mods[m].indexes for m in m_of],
+                                          extra=prov)
+                    est, cols, lds_s = res[:3]
+                    est, cols, lds_cand = est[sl_dev], cols[:, sl_dev], [float(lds_s[c]) for c in slot_of]
+                    if len(res) == 5:
+                        q_lat_prev[t, -1, ld] = res[3]
+                        lds_prov = res[4]
+                else:
+                    est, cols, lds_cand = self._eager_candidates(ld, t, x, y, q_lat, n_hist)
+            if lds_prov is None:
+                q_lat_prev[:, -1, ld] = prov.compute_q_lat_all(n_hist, h_ini=1.0)
+                lds_prov = float(prov.return_LDS_param_likelihood())
             prov._defer_checks = False
             prov._check_pending()
-            birth_best = int(host[0]) == M                           # the new cluster scores the beat best: is it worth it?
-            lds_prov = float(host[1])
-            _tick("prov")
-            order = q_ord.tolist() if birth_best else []
+            _tick("candidates")
             # score tables of every evaluation of this beat: [0] current clusters, [1] with the new cluster, [2 + r] the r best
             # clusters tried so far with the beat added (the reference's q_post is cumulative over its loop, GPI_HDP.py:2040-2075)
             Qb, Lb = self.weight_mean(q_aux), self.weight_mean(q_lat)
             Qs, Ls = [Qb, self.weight_mean(q_prev)], [Lb, self.weight_mean(q_lat_prev)]
-            lds_cur = [g.lds_param_likelihood_value() for g in self.gpmodels[ld]]
-            lds_cand = None
             if order:
-                if pool is not None:
-                    m_of = np.argsort(slot_of)                         # cluster index of every slot
-                    est, cols, lds_s = pool.candidates(t, q_lat[:, ops.to_dev(m_of, torch.int64, dev), ld].contiguous(),
-                                                       [mods[m].indexes for m in m_of])
-                    est, cols, lds_cand = est[sl_dev], cols[:, sl_dev], [float(lds_s[c]) for c in slot_of]
-                else:
-                    est, cols, lds_cand = self._eager_candidates(ld, t, x, y, q_lat, n_hist)
-                _tick("candidates")
                 R = len(order)
                 od = ops.to_dev(order, torch.int64, dev)
                 tried = torch.zeros((R, K), dtype=torch.bool, device=dev)             # tried[r, m]: cluster m is among the r + 1 best

@@ -182,7 +182,7 @@ class EagerPool:
         sc = torch.stack([sl.g.log_sq_error(sl.g.x_basis, self._y, i=-1) for sl in self.slots])
         return sc, torch.zeros(len(self.slots), dtype=torch.int32)
 
-    def candidates(self, t_new, q_lat_cols, indexes):
+    def candidates(self, t_new, q_lat_cols, indexes, extra=None):
         import types
         import hdpgpc_amd.GPI_HDP as H
         est, cols, lds = [], [], []
