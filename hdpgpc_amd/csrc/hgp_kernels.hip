@@ -827,10 +827,18 @@ struct Rank1Args {
   const double* beta;
   int T, b;
   int32_t* info;
+  unsigned long long* stamps;   // diagnostic builds (HGP_STAMPS) only
 };
 
-__global__ __launch_bounds__(256) void k_chol_rank1(Rank1Args a) {
+// COAL (T even): the row segments move as full 128-byte lines - lane l of a wave takes 16 bytes (chunk l & 7) of row 8 u + (l >> 3),
+// u = 0 .. 7, so one load / store instruction covers 8 complete lines instead of 16 bytes of 64 different ones - and are
+// transposed to "thread i owns row i" through a per-wave LDS tile.  (The direct form re-fetched every line eight times: eight
+// waves x 64 lines x 128 bytes per block do not stay in the 32 KB L1.)
+constexpr int R1_LD = 18;   // doubles per row of the transpose tile (16 + 2: 144-byte stride)
+template <bool COAL>
+__global__ __launch_bounds__(256, 2) void k_chol_rank1(Rank1Args a) {
   __shared__ double rot[2][16][4];   // (1/c, s, c) of the 16 steps of a block
+  __shared__ __attribute__((aligned(16))) double tile_all[COAL ? 4 * 64 * R1_LD : 2];
   __shared__ int s_info;
   const int i = threadIdx.x, lane = i & 63;
   const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
@@ -844,14 +852,45 @@ __global__ __launch_bounds__(256) void k_chol_rank1(Rank1Args a) {
   int info = 0;
   const int nblk = (T + 15) >> 4;
   double cur[16], nxt[16];
+  double* tile = tile_all + (COAL ? wave * 64 * R1_LD : 0);
+  const int q8 = lane >> 3, ch = lane & 7;          // COAL: my sub-row and 16-byte chunk
+  // COAL: block kc of my wave's 64 rows -> nxt[2 u], nxt[2 u + 1] = columns 16 kc + 2 ch, + 1 of row 64 wave + 8 u + q8
+  auto fetch = [&](int kc) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) cur[j] = (i < T && j < T && j <= i) ? L[(size_t)i * T + j] : 0.0;
+    for (int u = 0; u < 8; ++u) {
+      const int row = 64 * wave + 8 * u + q8, col = 16 * kc + 2 * ch;
+      double2 v = make_double2(0.0, 0.0);   // (branches: lanes with nothing to fetch issue nothing - faster here than the branch-free
+      if (row < T && row >= 16 * kc && col <= row && col + 1 < T) v = *reinterpret_cast<const double2*>(L + (size_t)row * T + col);   // form, 0.051 vs 0.063 ms at T = 128)
+      else if (row < T && row >= 16 * kc && col <= row && col < T) v.x = L[(size_t)row * T + col];
+      nxt[2 * u] = v.x;
+      nxt[2 * u + 1] = v.y;
+    }
+  };
+  auto to_rows = [&](int kc) {                      // nxt (line layout) -> cur (thread i owns row i), upper part zero
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<double2*>(tile + (8 * u + q8) * R1_LD + 2 * ch) = make_double2(nxt[2 * u], nxt[2 * u + 1]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] = (16 * kc + j <= i) ? tile[lane * R1_LD + j] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+  };
+  if constexpr (COAL) {
+    fetch(0);
+    to_rows(0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] = (i < T && j < T && j <= i) ? L[(size_t)i * T + j] : 0.0;
+  }
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = 16 * kb, k1 = k0 + 16;
     const bool below = i < T && i >= k0;            // rows above the block are final
     if (kb + 1 < nblk) {
+      if constexpr (COAL) {
+        fetch(kb + 1);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) nxt[j] = (i < T && i >= k1 && k1 + j <= i) ? L[(size_t)i * T + k1 + j] : 0.0;
+        for (int j = 0; j < 16; ++j) nxt[j] = (i < T && i >= k1 && k1 + j <= i) ? L[(size_t)i * T + k1 + j] : 0.0;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) cur[j] *= sa;
@@ -905,14 +944,188 @@ __global__ __launch_bounds__(256) void k_chol_rank1(Rank1Args a) {
         }
       }
     }
-    if (below) {
+    if constexpr (COAL) {
+      if (64 * wave + 63 >= k0) {                     // (wave-uniform) some of my rows are at or below the block
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (k0 + j <= i) L[(size_t)i * T + k0 + j] = cur[j];
+        for (int j = 0; j < 16; ++j) tile[lane * R1_LD + j] = cur[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = 64 * wave + 8 * u + q8, col = k0 + 2 * ch;
+          const double2 v = *reinterpret_cast<const double2*>(tile + (8 * u + q8) * R1_LD + 2 * ch);
+          if (row < T && row >= k0 && col + 1 <= row) *reinterpret_cast<double2*>(L + (size_t)row * T + col) = v;
+          else if (row < T && row >= k0 && col <= row) L[(size_t)row * T + col] = v.x;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (kb + 1 < nblk) to_rows(kb + 1);
+    } else {
+      if (below) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (k0 + j <= i) L[(size_t)i * T + k0 + j] = cur[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
     }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
   }
+  if (info != 0 && lane == 0) {                 // the earliest bad pivot over the waves wins (a bad alpha/beta stays -1)
+    const int old = atomicCAS(&s_info, 0, info);
+    if (old > info) atomicMin(&s_info, info);
+  }
+  __syncthreads();
+  if (i == 0 && a.info) a.info[m] = s_info;
+}
+
+// The pipelined form (T even, shipped).  What k_chol_rank1<true> does per block - pivot chain, barrier, everybody applies the 16
+// rotations, stores, transposes the next segment - is one serial 12 k cycles (5 us) per block: 83 us per factor with the CU to
+// itself (in-kernel stamps, tools/stamps_rank1.py).  But block kb's chain needs nothing from block kb - 1 except x of ITS OWN
+// sixteen rows, which the pivot wave updates itself inside the chain; the fresh columns of L do not depend on earlier rotations.
+// So in iteration kb the pivot wave runs chain(kb) while the other waves apply the rotations of block kb - 1 (published at the
+// previous barrier; one buffer per block, no reuse hazard), store that block and bring in the next one; the pivot wave does its own
+// loads and stores BEHIND its chain.  Critical path per block: two LDS transposes + the 16 dependent steps + one barrier.
+// Same arithmetic per element as the other two forms: results identical bit for bit.
+__global__ __launch_bounds__(256, 2) void k_chol_rank1_pipe(Rank1Args a) {
+  __shared__ __attribute__((aligned(16))) double rot[16][16][4];   // [block][step] (1/c, s, c, -); identity for steps >= T
+  __shared__ __attribute__((aligned(16))) double tile_all[4 * 64 * R1_LD];
+  __shared__ int s_info;
+  const int i = threadIdx.x, lane = i & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
+  const int m = blockIdx.x;
+  const int T = a.T;
+  double* L = a.L + (size_t)m * T * T;
+  const double al = a.alpha ? a.alpha[m] : 1.0, be = a.beta ? a.beta[m] : 1.0;
+  const double sa = sqrt(al), sb = sqrt(be);
+  double x = (i < T) ? sb * a.v[(size_t)m * T + i] : 0.0;
+  if (i == 0) s_info = (al > 0.0 && be >= 0.0) ? 0 : -1;
+  int info = 0;
+  const int nblk = (T + 15) >> 4;
+  double cur[16];
+  double2 ln8[8];   // eight 16-byte pieces in line layout: the fetched block on its way in
+  double* tile = tile_all + wave * 64 * R1_LD;
+  const int q8 = lane >> 3, ch = lane & 7;
+  const int last = min(nblk - 1, (64 * wave + 63) >> 4);   // the last block that reaches rows of this wave
+  // piece u of a block: columns 16 kc + 2 ch, + 1 of row 64 wave + 8 u + q8
+  size_t off[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) off[u] = (size_t)min(64 * wave + 8 * u + q8, T - 1) * T + 2 * ch;
+  // no branches: a lane with nothing to fetch reads L[0] (a conditional load is waited for at once - eight serial round trips)
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = 64 * wave + 8 * u + q8, col = 16 * kc + 2 * ch;
+      const bool on = row < T && row >= 16 * kc && col <= row && col < T;      // (T even: col + 1 < T as well)
+      const double2 v = *reinterpret_cast<const double2*>(L + (on ? off[u] + 16 * kc : (size_t)0));
+      ln8[u] = on ? v : make_double2(0.0, 0.0);
+    }
+  };
+  // ln8 -> cur (thread i owns row i) scaled by sqrt(alpha).  Entries right of the diagonal inside a fetched piece are whatever the
+  // caller's upper triangle holds: no step reads them (rotation k touches rows > k only) and put_rows never stores them
+  auto to_rows = [&]() {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<double2*>(tile + (8 * u + q8) * R1_LD + 2 * ch) = ln8[u];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] = tile[lane * R1_LD + j] * sa;
+    __builtin_amdgcn_wave_barrier();
+  };
+  double2 out8[8];   // the finished block on its way out
+  auto rows_to_lines = [&]() {   // cur (final) -> out8
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[lane * R1_LD + j] = cur[j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) out8[u] = *reinterpret_cast<const double2*>(tile + (8 * u + q8) * R1_LD + 2 * ch);
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto put_rows = [&](int kc) {
+    const int k0 = 16 * kc;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = 64 * wave + 8 * u + q8, col = k0 + 2 * ch;
+      if (row < T && row >= k0 && col + 1 <= row) *reinterpret_cast<double2*>(L + off[u] + k0) = out8[u];
+      else if (row < T && row >= k0 && col <= row) L[off[u] + k0] = out8[u].x;
+    }
+  };
+#ifdef HGP_STAMPS   // where do the iterations go?  per wave: [0] apply + transposes, [1] chain, [2] loads / stores issued, [3] barrier wait
+  unsigned long long st_acc[4] = {0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
+#define HGP_R1(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long n_ = __builtin_readcyclecounter(); st_acc[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define HGP_R1(i)
+#endif
+  fetch(0);
+  to_rows();
+  if (1 <= last) fetch(1);
+  __syncthreads();   // s_info
+  HGP_R1(0);
+#pragma nounroll
+  for (int kb = 0; kb <= nblk; ++kb) {
+    const bool have_prev = kb >= 1 && kb - 1 <= last;
+    // A. block kb - 1: apply its rotations (its pivot wave did so inside the chain), turn it into lines; block kb into rows
+    if (have_prev) {
+      const int kp = kb - 1, wdp = (16 * kp) >> 6;
+      if (wave > wdp) {
+        const double4* R = reinterpret_cast<const double4*>(&rot[kp][0][0]);
+        double4 rr[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) rr[k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const double lnv = fma(rr[k].y, x, cur[k]) * rr[k].x;
+          x = fma(rr[k].z, x, -rr[k].y * lnv);
+          cur[k] = lnv;
+        }
+      }
+      rows_to_lines();
+      if (kb <= last) to_rows();
+    }
+    HGP_R1(0);
+    const bool pivot = kb < nblk && wave == ((16 * kb) >> 6);
+    if (!pivot && have_prev) {
+      put_rows(kb - 1);
+      if (kb + 1 <= last) fetch(kb + 1);
+      HGP_R1(2);
+    }
+    // B. the pivot chain of block kb
+    if (pivot) {
+      const int k0 = 16 * kb, pl0 = k0 & 63;
+      double (*R)[4] = rot[kb];
+      double mine = 1.0;   // reciprocal of MY pivot entry (lane pl0 + j holds l_jj in cur[j]), off the dependent chain
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mine = (lane == pl0 + j) ? cur[j] : mine;
+      const double myinv = 1.0 / mine;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {   // (columns >= T of the last block hold zeros: l_kk = 0 -> NaN, replaced by the identity below)
+        const int pl = pl0 + k;
+        const double lkk = lane_bcast(cur[k], pl), xk = lane_bcast(x, pl), ilkk = lane_bcast(myinv, pl);
+        const double t = fma(lkk, lkk, xk * xk);
+        const double rinv = rsqrt_nr(t);
+        const double r = t * rinv, cinv = lkk * rinv, c = r * ilkk, sn = xk * ilkk;
+        const bool live = k0 + k < T;
+        info = (live && !(r > 0.0) && info == 0) ? k0 + k + 1 : info;
+        const bool upd = live && lane > pl && i < T;
+        const double lnv = fma(sn, x, cur[k]) * cinv;
+        const double xn = fma(c, x, -sn * lnv);
+        x = upd ? xn : x;
+        cur[k] = (live && lane == pl) ? r : (upd ? lnv : cur[k]);
+        // lanes 0 and 1 publish the rotation (16 bytes each); steps beyond T are the identity, so nobody has to test for them.
+        // (Measured and dropped: lanes 4 k .. 4 k + 2 keeping the values by selects and one store per block - 0.190 vs 0.182 ms.)
+        const double2 w = (lane == 0) ? make_double2(live ? cinv : 1.0, live ? sn : 0.0) : make_double2(live ? c : 1.0, 0.0);
+        if (lane < 2) *reinterpret_cast<double2*>(&R[k][2 * lane]) = w;
+      }
+      HGP_R1(1);
+      if (have_prev) put_rows(kb - 1);
+      if (kb + 1 <= last) fetch(kb + 1);
+      HGP_R1(2);
+    }
+    __syncthreads();
+    HGP_R1(3);
+  }
+#ifdef HGP_STAMPS
+  if (a.stamps && m == 0 && lane == 0)
+    for (int q = 0; q < 4; ++q) atomicAdd(&a.stamps[4 * wave + q], st_acc[q]);
+#endif
+#undef HGP_R1
   if (info != 0 && lane == 0) {                 // the earliest bad pivot over the waves wins (a bad alpha/beta stays -1)
     const int old = atomicCAS(&s_info, 0, info);
     if (old > info) atomicMin(&s_info, info);
@@ -2101,8 +2314,16 @@ int hgp_chol_rank1_f64(double* L, const double* v, const double* alpha, const do
   if (!L || !v || T <= 0 || b < 0) return -1;
   if (b == 0) return 0;
   if (T > 256) return -2;
-  Rank1Args a{L, v, alpha, beta, T, b, info};
-  hipLaunchKernelGGL(k_chol_rank1, dim3(b), dim3(64 * ((T + 63) / 64)), 0, (hipStream_t)stream, a);
+  Rank1Args a{L, v, alpha, beta, T, b, info, nullptr};
+#ifdef HGP_STAMPS
+  a.stamps = hgp_internal_stamp_dev;
+#endif
+  if (T % 2 == 0 && !env_on("HGP_RANK1_DIRECT") && !env_on("HGP_RANK1_COAL") && (T >= 192 || env_on("HGP_RANK1_PIPE")))
+    hipLaunchKernelGGL(k_chol_rank1_pipe, dim3(b), dim3(64 * ((T + 63) / 64)), 0, (hipStream_t)stream, a);
+  else if (T % 2 == 0 && !env_on("HGP_RANK1_DIRECT"))
+    hipLaunchKernelGGL(k_chol_rank1<true>, dim3(b), dim3(64 * ((T + 63) / 64)), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_chol_rank1<false>, dim3(b), dim3(64 * ((T + 63) / 64)), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -134,7 +134,8 @@ def test_offline_trace_q_matrix_and_assignments():
 
 def test_chol_rank1_config5():
     rng = np.random.default_rng(8)
-    for T, b in ((30, 3), (90, 4), (256, 2)):
+    # every form of the kernel: odd T (one row segment per thread), even T < 192 (full lines through LDS), even T >= 192 (pipelined)
+    for T, b in ((30, 3), (90, 4), (256, 2), (64, 5), (192, 3), (250, 2), (255, 2), (208, 9)):
         Q = rng.normal(size=(b, T, T))
         A = Q @ Q.transpose(0, 2, 1) / T + np.eye(T)
         L = np.linalg.cholesky(A)
@@ -145,6 +146,17 @@ def test_chol_rank1_config5():
         for k in range(b):
             ref = orc.chol_rank1_update(L[k], v[k], al[k], be[k])
             assert np.allclose(Ln[k].cpu().numpy(), ref, rtol=1e-10, atol=1e-11)
+        # the strict upper triangle belongs to the caller: never read into a result, never written
+        Lp = L + np.triu(np.full((T, T), np.nan), 1)
+        Lq, info = ops.chol_rank1(dev(Lp), dev(v), al, be)
+        assert int(info.abs().max()) == 0
+        Lq = Lq.cpu().numpy()
+        assert np.array_equal(np.tril(Lq), np.tril(Ln.cpu().numpy())) and np.all(np.isnan(Lq[:, np.triu_indices(T, 1)[0], np.triu_indices(T, 1)[1]]))
+    # a factor that loses positive definiteness reports the first bad pivot, as the other forms do
+    T = 256
+    L = np.linalg.cholesky(np.eye(T) * 2.0)[None]
+    Lb, info = ops.chol_rank1(dev(L), dev(np.ones((1, T))), np.array([1.0]), np.array([-1.0]))
+    assert int(info[0]) == -1
 
 
 def test_gemm_batched_shapes():
