@@ -240,7 +240,7 @@ def secondary_pairs_t90(dev, ops, synth, N=2048, K=8, T=90, reps=10):
     assert int(info.abs().max()) == 0 and bool(torch.isfinite(quad).all())
     ms = e0.elapsed_time(e1) / reps
     tf = N * K * algorithmic_flops_per_eval(T) / (ms * 1e-3) / 1e12
-    return {"workload": f"per-pair path at the records' size: {N} segments x {K} clusters, T={T}, irregular grids (k_pairs<6>)",
+    return {"workload": f"per-pair path at the records' size: {N} segments x {K} clusters, T={T}, irregular grids (k_pairs<6, true>, eight waves per workgroup = two per SIMD)",
             "value": N * K / (ms * 1e-3), "unit": "evals/s", "kernel_ms": ms,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": algorithmic_flops_per_eval(T)}}
@@ -313,7 +313,7 @@ def secondary_rank1(dev, ops, b=1024, T=256, reps=5):
     assert int(info.abs().max()) == 0
     ms = e0.elapsed_time(e1) / reps
     gbs = b * 8.0 * T * T / (ms * 1e-3) / 1e9
-    return {"workload": f"configs[4] kernel: rank-1 Cholesky update of {b} factors, T={T} (k_chol_rank1)",
+    return {"workload": f"configs[4] kernel: rank-1 Cholesky update of {b} factors, T={T} (k_chol_rank1_pipe; opt-in kernel, see DESIGN.md section 0)",
             "value": b / (ms * 1e-3), "unit": "updates/s", "kernel_ms": ms,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
 

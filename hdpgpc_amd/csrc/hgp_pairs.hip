@@ -31,9 +31,18 @@ namespace {
 
 constexpr int PAIRS_DCOLS = 16;   // clusters whose d = y - E^T a' one pass of the workgroup prepares (one MFMA column block)
 
-template <int NB>
+// Waves per workgroup of k_pairs<NB, BAND>.  One workgroup per segment, its waves take the clusters round-robin; E (16 NB)^2 doubles
+// of LDS) allows one workgroup per CU from NB = 6 on, i.e. ONE wave per SIMD at four waves: every latency of the pair - the pivot
+// chain of the six diag16 first of all - is idle time.  The band kernel at NB = 6 (the records' T = 90) fits 256 registers once
+// the sweep-1 operand ring holds two half-blocks instead of eight, so EIGHT waves share the segment's E: two per SIMD.
+#ifndef HGP_PAIRS_W8_NB
+#define HGP_PAIRS_W8_NB 6   // the NB whose band kernel runs eight waves per workgroup (0: none)
+#endif
+template <int NB, bool BAND>
+constexpr int pairs_waves() { return (BAND && NB == HGP_PAIRS_W8_NB) ? 8 : WAVES; }
+template <int NB, int PW = WAVES>
 constexpr size_t pairs_lds_bytes() {
-  return sizeof(double) * ((size_t)(16 * NB) * (16 * NB) + 3 * 16 * NB + WAVES * DIAG_SCR + PAIRS_DCOLS * 16 * NB) +
+  return sizeof(double) * ((size_t)(16 * NB) * (16 * NB) + 3 * 16 * NB + PW * DIAG_SCR + PAIRS_DCOLS * 16 * NB) +
          sizeof(int) * 32;
 }
 
@@ -123,7 +132,7 @@ struct PairsBand {
   }
 };
 
-template <int NB>
+template <int NB, int RD_>
 __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const double* __restrict__ Mu, const double* E,
                                             int lane_in, double cc, double noise, int Ts
 #ifdef HGP_STAMPS
@@ -132,10 +141,7 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
 ) {
   using PB = PairsBand<NB>;
   constexpr int TP = 16 * NB, NH = NB / 2, NI = PB::nitems();
-#ifndef HGP_BAND_RING
-#define HGP_BAND_RING ((NB <= 6) ? 8 : 4)
-#endif
-  constexpr int RD = HGP_BAND_RING;   // ring slots (half-blocks in flight): NB <= 6 has the registers for eight
+  constexpr int RD = RD_;   // ring slots (half-blocks in flight): NB <= 6 has the registers for eight at one wave per SIMD
   double ra[RD][2][NH], re[RD][2];
   d4 BJ[NH];
   // Every operand address of the sweeps is  (uniform base + compile-time constant) + ONE of two lane offsets: Mu is uniform
@@ -245,8 +251,12 @@ __device__ __forceinline__ void band_sweeps(d4 (&cov)[NB * (NB + 1) / 2], const 
 // mask-driven sweeps, launched right behind on the same grid) takes the listed segments; its other workgroups leave at once.  With both sweep codes in one
 // kernel the allocator spilled 126 VGPRs at NB = 8 (284 B of scratch per lane, 189 MB of scratch writes per launch, WRITE_SIZE);
 // apart they need none.  Without a list (a.fb == nullptr: NB < 6, HGP_PAIRS_GENERIC=1) the generic kernel takes every segment.
+#ifndef HGP_PAIRS_OCC2_NB
+#define HGP_PAIRS_OCC2_NB 4   // largest NB built for two workgroups per CU (<= 256 VGPRs)
+#endif
 template <int NB, bool BAND>
-__global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsArgs a) {   // T <= 64: two workgroups per CU (the kernel sat 3 registers above that limit)
+__global__ __launch_bounds__((64 * pairs_waves<NB, BAND>()), ((NB <= HGP_PAIRS_OCC2_NB) ? 2 : 1)) void k_pairs(PairsArgs a) {   // T <= 64: two workgroups per CU (the kernel sat 3 registers above that limit)
+  constexpr int PW = pairs_waves<NB, BAND>();
   constexpr int TP = 16 * NB;
   constexpr int NH = NB / 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
   double* xbs = ys + TP;          // basis grid / ell
   const int tid = threadIdx.x, wave = tid >> 6;
   double* scr = xbs + TP + wave * DIAG_SCR;
-  double* dall = xbs + TP + WAVES * DIAG_SCR;   // [PAIRS_DCOLS][TP]: d = y - E^T a' of the clusters of the current chunk, then z = L^{-1} d
+  double* dall = xbs + TP + PW * DIAG_SCR;   // [PAIRS_DCOLS][TP]: d = y - E^T a' of the clusters of the current chunk, then z = L^{-1} d
   int* amask = reinterpret_cast<int*>(dall + PAIRS_DCOLS * TP);   // bit Kt of amask[J]: block (Kt, J) of E active
   const int T = a.T, Ts = a.Ts;
   HGP_STAMP_DECL
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
 
   // Padding (i >= Ts, k >= T) uses far-apart sentinels instead of bounds predicates: every kernel entry that
   // involves a padded point is then exp(-huge) = 0 by itself (all differences stay finite: < 3e152).
-  for (int i = tid; i < TP; i += 64 * WAVES) {
+  for (int i = tid; i < TP; i += 64 * PW) {
     xs[i] = (i < Ts) ? a.x[(size_t)n * Ts + i] / a.ell : 1e150 * (double)(1 + i);
     ys[i] = (i < Ts) ? a.y[(size_t)n * Ts + i] : 0.0;
     xbs[i] = (i < T) ? a.xb[i] / a.ell : -1e150 * (double)(1 + i);
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
   { unsigned long long n_ = __builtin_readcyclecounter(); hgp_acc_[8] += n_ - hgp_t_; }
 #endif
   {
-    // Wave w owns the column blocks Jb = w, w + WAVES, ...: it tests every block (Kt, Jb) of E and every tile (I <= Jb, Jb) of K**
+    // Wave w owns the column blocks Jb = w, w + PW, ...: it tests every block (Kt, Jb) of E and every tile (I <= Jb, Jb) of K**
     // against the cut-off and builds the active blocks.  The lane's rows of both grids sit in registers after ONE LDS round trip
     // (the loop over blocks used to wait for five LDS reads per block: 19 k cycles for the two test loops, in-kernel stamps),
     // and the masks of a column are plain stores by its owner (no atomics).
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
         xsr[Kt][r] = xs[16 * Kt + g + 4 * r];
       }
     }
-    for (int Jb = wave; Jb < NB; Jb += WAVES) {
+    for (int Jb = wave; Jb < NB; Jb += PW) {
       const int j = 16 * Jb + c;
       const double xj = xs[j];
       unsigned am = 0, a4 = 0, km = 0;
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
 #endif
   if (kcache) {
     const int lane = tid & 63, g = lane >> 4, c = lane & 15;
-    for (int t = wave; t < NB * NB; t += WAVES) {
+    for (int t = wave; t < NB * NB; t += PW) {
       const int I = t / NB, J = t % NB;
       if (I > J || !((kmask[J] >> I) & 1)) continue;
       const int Kh = (I + NH) % NB;
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
     const int g = lane >> 4, c = lane & 15;
     const bool col = ch + c < Kg;
     const double* apc = a.ap + (size_t)(col ? a.perm[a.kbeg + ch + c] : 0) * TP + g;
-    for (int Jb = wave; Jb < NB; Jb += WAVES) {
+    for (int Jb = wave; Jb < NB; Jb += PW) {
       const int mJ = __builtin_amdgcn_readfirstlane(amask[Jb]);
       d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
   }
   __syncthreads();
   const int kk_end = (a.kbeg + ch + PAIRS_DCOLS < a.kend) ? a.kbeg + ch + PAIRS_DCOLS : a.kend;
-  for (int kk = a.kbeg + ch + wave; kk < kk_end; kk += WAVES) {
+  for (int kk = a.kbeg + ch + wave; kk < kk_end; kk += PW) {
     const int lane = launder(tid) & 63;
     const int g = lane >> 4, c = lane & 15;
     const int kc = BAND ? __builtin_amdgcn_readfirstlane(a.perm[kk]) : a.perm[kk];   // band kernel: uniform, the per-cluster bases are scalar
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB <= 4) ? 2 : 1) void k_pairs(PairsAr
     const double* Mbase = a.Mp + (size_t)kc * TP * TP + (size_t)g * TP;   // + column offset inside HGP_FILL (interleaved)
 #endif
     if constexpr (BAND) {
-      band_sweeps<NB>(cov, a.Mp + (size_t)kc * TP * TP, E, lane, cc, noise, Ts
+      band_sweeps<NB, (PW > WAVES) ? 2 : ((NB <= 6) ? 8 : 4)>(cov, a.Mp + (size_t)kc * TP * TP, E, lane, cc, noise, Ts
 #ifdef HGP_STAMPS
                       , hgp_t_, hgp_acc_
 #endif
@@ -1113,7 +1123,9 @@ int launch_pairs(const PairsArgs& a0, hipStream_t st) {
     hipLaunchKernelGGL((k_pairs<NB, false>), dim3(a.N), dim3(64 * WAVES), lds, st, a);
     return launch_status();
   }
-  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs<NB, true>), lds)) return rc_;
+  constexpr int PWB = pairs_waves<NB, true>();
+  const size_t ldsb = pairs_lds_bytes<NB, PWB>();
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_pairs<NB, true>), ldsb)) return rc_;
   for (int off = 0; off < a0.N; off += PAIRS_FB_CAP) {   // the fall-back list holds PAIRS_FB_CAP segments
     PairsArgs a = a0;
     a.N = std::min(PAIRS_FB_CAP, a0.N - off);
@@ -1125,7 +1137,7 @@ int launch_pairs(const PairsArgs& a0, hipStream_t st) {
     a.out_quad += oo;
     if (a.out_logdet) a.out_logdet += oo;
     if (a.out_info) a.out_info += oo;
-    hipLaunchKernelGGL((k_pairs<NB, true>), dim3(a.N), dim3(64 * WAVES), lds, st, a);
+    hipLaunchKernelGGL((k_pairs<NB, true>), dim3(a.N), dim3(64 * PWB), ldsb, st, a);
     const int rc1 = launch_status();
     hipLaunchKernelGGL((k_pairs<NB, false>), dim3(a.N), dim3(64 * WAVES), lds, st, a);
     const int rc2 = launch_status();
