@@ -1644,7 +1644,9 @@ __device__ __forceinline__ void df_wait_all_ge(int* tdone, int v, int lane, int*
 //  * the wave that will factor the next diagonal block polls for W_K without sleeping.
 // (Measured and dropped: the SIMD-mate of the wave on the pivot chain holding its MFMAs back while the chain runs - f64 MFMA and
 //  VALU instructions of two waves on one SIMD do not overlap - is SLOWER, 3.93 vs 3.69 ms per 8 192 pairs at T = 256: the polls
-//  cost every tile update an LDS round trip; s_setprio(3) on the chain wave is worth 0.7 %.)
+//  cost every tile update an LDS round trip; s_setprio(3) on the chain wave is worth 0.7 %.  Round 4 tried it again with the flag
+//  read issued together with the LDS tile the update needs anyway (no extra round trip), the mate sleeping only while diag16_acc
+//  runs: 14.16 vs 13.34 ms per 32 768 pairs - the MFMA time the mate loses is not given back by the shorter chain.)
 template <int NB>
 __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double* row0, double* row1, double* row2, double* Wall,
                                                   double* scr, int* flags, int wave, int lane_in, PivotAcc& pa, int n, double* dvec) {
