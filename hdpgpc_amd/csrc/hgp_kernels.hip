@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_rank1(Rank1Args a) {
 // loads and stores BEHIND its chain.  Critical path per block: two LDS transposes + the 16 dependent steps + one barrier.
 // Same arithmetic per element as the other two forms: results identical bit for bit.
 __global__ __launch_bounds__(256, 2) void k_chol_rank1_pipe(Rank1Args a) {
-  __shared__ __attribute__((aligned(16))) double rot[16][16][4];   // [block][step] (1/c, s, c, -); identity for steps >= T
+  __shared__ __attribute__((aligned(16))) double rot[16][16][4];   // [block][step] (1/c, s, c, -)
   __shared__ __attribute__((aligned(16))) double tile_all[4 * 64 * R1_LD];
   __shared__ int s_info;
   const int i = threadIdx.x, lane = i & 63;
@@ -1071,9 +1071,11 @@ __global__ __launch_bounds__(256, 2) void k_chol_rank1_pipe(Rank1Args a) {
         for (int k = 0; k < 16; ++k) rr[k] = R[k];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          const double lnv = fma(rr[k].y, x, cur[k]) * rr[k].x;
-          x = fma(rr[k].z, x, -rr[k].y * lnv);
-          cur[k] = lnv;
+          if (16 * kp + k < T) {   // (uniform)
+            const double lnv = fma(rr[k].y, x, cur[k]) * rr[k].x;
+            x = fma(rr[k].z, x, -rr[k].y * lnv);
+            cur[k] = lnv;
+          }
         }
       }
       rows_to_lines();
@@ -1094,8 +1096,9 @@ __global__ __launch_bounds__(256, 2) void k_chol_rank1_pipe(Rank1Args a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) mine = (lane == pl0 + j) ? cur[j] : mine;
       const double myinv = 1.0 / mine;
+      const unsigned rbase = (unsigned)(unsigned long long)(&R[0][0]);   // LDS offset = low half of the flat address
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {   // (columns >= T of the last block hold zeros: l_kk = 0 -> NaN, replaced by the identity below)
+      for (int k = 0; k < 16; ++k) {   // (columns >= T of the last block hold zeros: l_kk = 0 -> NaN rotations that no row uses)
         const int pl = pl0 + k;
         const double lkk = lane_bcast(cur[k], pl), xk = lane_bcast(x, pl), ilkk = lane_bcast(myinv, pl);
         const double t = fma(lkk, lkk, xk * xk);
@@ -1108,11 +1111,20 @@ __global__ __launch_bounds__(256, 2) void k_chol_rank1_pipe(Rank1Args a) {
         const double xn = fma(c, x, -sn * lnv);
         x = upd ? xn : x;
         cur[k] = (live && lane == pl) ? r : (upd ? lnv : cur[k]);
-        // lanes 0 and 1 publish the rotation (16 bytes each); steps beyond T are the identity, so nobody has to test for them.
-        // (Measured and dropped: lanes 4 k .. 4 k + 2 keeping the values by selects and one store per block - 0.190 vs 0.182 ms.)
-        const double2 w = (lane == 0) ? make_double2(live ? cinv : 1.0, live ? sn : 0.0) : make_double2(live ? c : 1.0, 0.0);
-        if (lane < 2) *reinterpret_cast<double2*>(&R[k][2 * lane]) = w;
+        // lane 0 publishes the rotation (the same number in every lane): three stores under exec = 1, in assembly - the compiler's
+        // form of "if (lane < 2) store" (two selects per value, s_and_saveexec, branch) was 1.8 k of the 5.3 k cycles of a block,
+        // and keeping the values by selects for one store per block measured slower still (0.190 vs 0.182 ms)
+        {
+          unsigned long long ex_;
+          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\t"
+                       "ds_write_b64 %1, %2 offset:%5\n\tds_write_b64 %1, %3 offset:%6\n\tds_write_b64 %1, %4 offset:%7\n\t"
+                       "s_mov_b64 exec, %0"
+                       : "=&s"(ex_)
+                       : "v"(rbase), "v"(cinv), "v"(sn), "v"(c), "n"(32 * k), "n"(32 * k + 8), "n"(32 * k + 16)
+                       : "memory");
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stores above are invisible to the compiler's counters
       HGP_R1(1);
       if (have_prev) put_rows(kb - 1);
       if (kb + 1 <= last) fetch(kb + 1);
