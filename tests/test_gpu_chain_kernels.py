@@ -92,6 +92,38 @@ def test_chol_inverse_with_riding_right_hand_sides(T, rhs_trans):
     assert np.allclose(Y2[0].cpu().numpy(), Y[0].cpu().numpy(), rtol=1e-13, atol=0.0)
 
 
+@pytest.mark.parametrize("T", [17, 50, 64, 90, 100, 128])
+def test_chol_inverse_rhs_small_and_large_batches_agree_bit_for_bit(T):
+    """Few matrices take one workgroup per (matrix, panel) (k_coop_inv_rhs), many take one wave per panel (k_wave_inv_rhs): the same
+    tile arithmetic in the same order, so a matrix must come out identical whichever batch it rides in - including its info."""
+    from hdpgpc_amd import ops
+    rng = np.random.default_rng(100 + T)
+    nblk = (T + 15) // 16
+    big = 256 // (2 * nblk) + 5                        # beyond the cooperative kernel's one round of workgroups
+    Q = rng.normal(size=(big, T, T))
+    A = Q @ Q.transpose(0, 2, 1) / T + 0.5 * np.eye(T)
+    A[1] = -A[1]                                       # not positive definite
+    R = rng.normal(size=(big, T, T))
+    on = (np.arange(big) % 3 != 2).astype(np.int32)
+
+    def run(n, trans):
+        Z = torch.zeros((n, T, T), dtype=torch.float64, device="cuda")
+        Y = torch.zeros((n, T, T), dtype=torch.float64, device="cuda")
+        info = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        ops.chol_inverse_rhs(dev(A[:n]), Z, dev(R[:n]), Y, info, rhs_on=torch.as_tensor(on[:n], device="cuda"), rhs_trans=trans, add_diag=1e-8)
+        torch.cuda.synchronize()
+        return Z.cpu().numpy(), Y.cpu().numpy(), info.cpu().numpy()
+
+    for trans in (False, True):
+        Zs, Ys, Is = run(4, trans)
+        Zb, Yb, Ib = run(big, trans)
+        assert Is.tolist() == [0, 1, 0, 0] and np.array_equal(Is, Ib[:4]) and not Ib[4:].any()
+        for m in (0, 2, 3):
+            assert np.array_equal(Zs[m], Zb[m]) and np.array_equal(Ys[m], Yb[m])
+        Lr = np.linalg.inv(np.linalg.cholesky(A[big - 1] + 1e-8 * np.eye(T)))
+        assert np.allclose(Zb[big - 1], Lr, rtol=1e-10, atol=1e-12 * np.abs(Lr).max())
+
+
 @pytest.mark.parametrize("T", [90, 144, 192, 256])
 def test_chol_inverse_only_up_to_256_with_caller_buffers(T):
     """hgp_chol_inverse_batched_f64: Z = L^-1 without touching A, caller-allocated outputs (the graphed member step), LAPACK-style
