@@ -220,6 +220,139 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_inv_rhs(InvRhsArgs a) {
   }
 }
 
+// ... and with the DATAFLOW factorisation (cooph_factor_df<NB, true>, NB / 2 waves per workgroup, NB = the even number of 16-blocks:
+// no padding at T = 90): no workgroup barrier inside the factorisation - the wave that owns block K + 1 solves only that panel tile,
+// updates its diagonal tile from the accumulator, factors it and publishes W_{K+1} and Z_{K+1} while the others are still in the
+// trailing update of step K.  The barrier version above spends 4.5 us per block step for 1.2 us of diag16_acc.
+template <int NB>
+__device__ __forceinline__ void cooph_load_sym_upper(d4 (&U)[CoopH<NB>::NT], const double* __restrict__ A, int ld, int n, int wave,
+                                                     int lane_in, double* scr_w) {
+  using C = CoopH<NB>;
+  // my block columns JA = wave (tiles I <= JA in slotA(I)) and JB = NB - 1 - wave (slotB(I)); both triangles are read as they lie
+  // (coalesced rows) and the lower one is transposed through a per-wave 16 x 18 LDS tile: U = 0.5 (A + A^T), identity padding
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+    const int J = h == 0 ? wave : NB - 1 - wave;
+    d4 nat[NB], trn[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      if (h == 0 && I >= C::NW) continue;           // column A only reaches block rows < NW
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;          // natural element of tile (I, J)
+        nat[I][r] = (I <= J && i < n && j < n) ? A[(size_t)i * ld + j] : 0.0;
+        const int i2 = 16 * J + g + 4 * r, j2 = 16 * I + c;        // natural element of tile (J, I)
+        trn[I][r] = (I < J && i2 < n && j2 < n) ? A[(size_t)i2 * ld + j2] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      if (h == 0 && I >= C::NW) continue;
+      const d4 src = (I == J) ? nat[I] : trn[I];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scr_w[(g + 4 * r) * DIAG_LD + c] = src[r];
+      __builtin_amdgcn_wave_barrier();
+      d4 v = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;
+        const double t = scr_w[c * DIAG_LD + g + 4 * r];
+        double x = 0.5 * (nat[I][r] + t);
+        if (!(i < n && j < n)) x = (i == j) ? 1.0 : 0.0;
+        if (I <= J) v[r] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (h == 0) U[C::slotA(I < C::NW ? I : 0)] = (I <= J) ? v : U[C::slotA(I < C::NW ? I : 0)];
+      else if (I <= J) U[C::slotB(I)] = v;
+    }
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64 * CoopH<NB>::NW) void k_cooph_inv_rhs(InvRhsArgs a) {
+  using C = CoopH<NB>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* row0 = smem;                       // three row buffers, W of every block, Z of every block: [NB] tiles each
+  double* Wall = row0 + 3 * NB * 256;
+  double* zbuf = Wall + NB * 256;
+  double* scr_all = zbuf + NB * 256;         // [NW][DIAG_SCR]
+  double* red = scr_all + C::NW * DIAG_SCR;  // [8]
+  int* flags = reinterpret_cast<int*>(red + 8);   // [16 + NB] + [8] status words
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int T = a.T, nblk = (T + 15) >> 4;
+  const int m = blockIdx.x, Jq = blockIdx.y;            // gridDim.y = 2 nblk: panels of L^-1, then panels of L^-1 op(B)
+  const bool is_rhs = Jq >= nblk;
+  const int Jc = is_rhs ? Jq - nblk : Jq;
+  const bool skip = (is_rhs && (!a.rhs || (a.rhs_on && a.rhs_on[m] == 0))) || (!is_rhs && !a.Linv);
+  if (skip) {
+    if (Jq == 0 && !a.Linv && threadIdx.x == 0 && a.info && (!a.rhs || (a.rhs_on && a.rhs_on[m] == 0))) a.info[m] = 0;
+    return;
+  }
+  double* scr = scr_all + wave * DIAG_SCR;
+  const double* A = a.A + (size_t)m * T * T;
+  d4 U[C::NT];
+#pragma unroll
+  for (int i_ = 0; i_ < C::NT; ++i_) U[i_] = (d4){0.0, 0.0, 0.0, 0.0};
+  cooph_load_sym_upper<NB>(U, A, T, T, wave, lane, scr);
+  {
+    double sh = a.add;
+    if (a.jitter_rel != 0.0) sh += a.jitter_rel * fmax(cooph_diag_abs_mean<NB>(U, T, wave, lane, a.add, red), F64_EPS);
+    if (sh != 0.0) cooph_add_diag<NB>(U, sh, T, wave, lane);
+  }
+  // my two tiles of the right-hand side panel: block rows JA = wave and JB = NB - 1 - wave
+  const double* B = is_rhs ? a.rhs + (size_t)m * T * T : nullptr;
+  d4 RA, RB;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int K = h == 0 ? wave : NB - 1 - wave;
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * K + g + 4 * r, j = 16 * Jc + c;
+      if (!is_rhs) v[r] = (K == Jc && g + 4 * r == c) ? 1.0 : 0.0;
+      else v[r] = (i < T && j < T) ? (a.rhs_trans ? B[(size_t)j * T + i] : B[(size_t)i * T + j]) : 0.0;
+    }
+    if (h == 0) RA = v;
+    else RB = v;
+  }
+  PivotAcc pa;
+  pa.init();
+  cooph_factor_df<NB, true>(U, row0, row0 + NB * 256, row0 + 2 * NB * 256, Wall, scr, flags, wave, lane, pa, T, nullptr, &RA, &RB, zbuf);
+  double* Z = (is_rhs ? a.rhs_out : a.Linv) + (size_t)m * T * T;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int K = h == 0 ? wave : NB - 1 - wave;
+    const d4 z = h == 0 ? RA : RB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * K + g + 4 * r, j = 16 * Jc + c;
+      if (i < T && j < T) Z[(size_t)i * T + j] = (is_rhs || K >= Jc) ? z[r] : 0.0;
+    }
+  }
+  if (Jq == (a.Linv ? 0 : nblk) && a.info) {   // the first panel sees every pivot: the earliest bad one over the waves
+    int* redi = flags + 16 + NB;
+    if (lane == 0) redi[wave] = pa.info;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int inf = 0;
+      for (int w = 0; w < C::NW; ++w)
+        if (redi[w] != 0 && (inf == 0 || redi[w] < inf)) inf = redi[w];
+      a.info[m] = inf;
+    }
+  }
+}
+
+template <int NB>
+int launch_cooph_inv_rhs(const InvRhsArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(double) * ((size_t)5 * NB * 256 + CoopH<NB>::NW * DIAG_SCR + 8) + sizeof(int) * (16 + NB + 8);
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_cooph_inv_rhs<NB>), lds)) return rc_;
+  hipLaunchKernelGGL(k_cooph_inv_rhs<NB>, dim3(a.b, 2 * ((a.T + 15) >> 4)), dim3(64 * CoopH<NB>::NW), lds, st, a);
+  return launch_status();
+}
+
 template <int NB>
 int launch_coop_inv_rhs(const InvRhsArgs& a, hipStream_t st) {
   const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
@@ -423,11 +556,19 @@ int hgp_chol_inverse_rhs_batched_f64(const double* A, int T, int b, double jitte
   InvRhsArgs a{A, T, b, jitter_rel, add_diag, Linv, rhs, rhs_on, rhs_trans, rhs_out, info};
   hipStream_t st = (hipStream_t)stream;
   // few matrices (the member step of a few chains): one workgroup per (matrix, panel) - latency; many: one wave each - throughput
-  // (tools/time_inv_rhs.py, per call: T = 128 51 -> 31 us, T = 90 30 -> 27 us, T = 50 16.5 -> 13 us while the workgroups fit the
-  // chip in one round - one per CU at T > 64; beyond that the one-wave kernel wins.  HGP_INV_COOP_MAX_WG overrides, 0 = never.)
+  // (tools/time_inv_rhs.py; while the workgroups fit the chip in one round - beyond that the one-wave kernel wins.
+  // HGP_INV_COOP_MAX_WG overrides the round size, 0 = never.)
   static const int coop_max_wg = getenv("HGP_INV_COOP_MAX_WG") ? atoi(getenv("HGP_INV_COOP_MAX_WG")) : 256;
-  if (T > 16 && (long)b * 2 * ((T + 15) >> 4) <= coop_max_wg)
-    return T <= 64 ? launch_coop_inv_rhs<4>(a, st) : launch_coop_inv_rhs<8>(a, st);
+  // T > 64: the dataflow form (T = 90: 21.7 us, barrier form 27.1, one wave per panel 30.3; T = 128: 28.0 / 30.6 / 51.5; two
+  // workgroups per CU at NB = 6); 32 < T <= 64: the barrier form (T = 50: 13.1 us against 14.7 / 16.5); T <= 32 is one wave anyway
+  const long wgs = (long)b * 2 * ((T + 15) >> 4);
+  if (T > 64 && wgs <= (nb_for(T) == 6 ? 2 : 1) * (long)coop_max_wg) {
+    static const bool barrier_form = env_on("HGP_INV_COOP_BARRIER");
+    if (barrier_form && wgs <= coop_max_wg) return launch_coop_inv_rhs<8>(a, st);
+    if (!barrier_form) return nb_for(T) == 6 ? launch_cooph_inv_rhs<6>(a, st) : launch_cooph_inv_rhs<8>(a, st);
+  } else if (T > 32 && T <= 64 && wgs <= coop_max_wg) {
+    return launch_coop_inv_rhs<4>(a, st);
+  }
   switch (nb_for(T)) {
     case 2: launch_inv_rhs<2>(a, st); break;
     case 4: launch_inv_rhs<4>(a, st); break;

@@ -1647,9 +1647,14 @@ __device__ __forceinline__ void df_wait_all_ge(int* tdone, int v, int lane, int*
 //  cost every tile update an LDS round trip; s_setprio(3) on the chain wave is worth 0.7 %.  Round 4 tried it again with the flag
 //  read issued together with the LDS tile the update needs anyway (no extra round trip), the mate sleeping only while diag16_acc
 //  runs: 14.16 vs 13.34 ms per 32 768 pairs - the MFMA time the mate loses is not given back by the shorter chain.)
-template <int NB>
+// RP (round 4): instead of the single vector dvec, a block column of 16 right-hand sides rides the factorisation (the inversions
+// of the member step, k_cooph_inv_rhs).  Tile I of it lives in the registers of the wave that owns block column I (*RAp for its column
+// JA, *RBp for JB); Z_K = W_K R_K is formed by the pivot wave right behind diag16_acc and published in zbuf ([NB] tiles of LDS)
+// together with W_K; R_J -= U_KJ^T Z_K follows each panel tile while it is still in its accumulator.  On exit the tiles hold L^-1 R.
+template <int NB, bool RP = false>
 __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double* row0, double* row1, double* row2, double* Wall,
-                                                  double* scr, int* flags, int wave, int lane_in, PivotAcc& pa, int n, double* dvec) {
+                                                  double* scr, int* flags, int wave, int lane_in, PivotAcc& pa, int n, double* dvec,
+                                                  d4* RAp = nullptr, d4* RBp = nullptr, double* zbuf = nullptr) {
   using C = CoopH<NB>;
   int* wdone = flags;
   int* tdone = flags + 1;        // [8]
@@ -1679,19 +1684,28 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
     const d4 Wd = diag16_sel<false>(U[C::diag_slot(K)], scr, lane, pa, 16 * K, nullptr, 0, n - 16 * K);
 #pragma unroll
     for (int s = 0; s < 4; ++s) Wall[(K * 4 + s) * 64 + lane] = Wd[s];
-    if constexpr (K > 0) {   // d_K -= sum over K' < K of U_K'K^T z_K' (deferred)
-      const double q = xrow_sum((K < C::NW) ? dpA : dpB);
-      if (g == 0) dvec[16 * K + c] -= q;
-      __builtin_amdgcn_wave_barrier();
-    }
-    double p = 0.0;   // z_K = W d_K
+    if constexpr (RP) {      // Z_K = W R_K
+      d4& rk = (K < C::NW) ? *RAp : *RBp;
+      d4 z = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) p = fma(Wd[s], dvec[16 * K + 4 * s + g], p);
-    p = xrow_sum(p);
-    __builtin_amdgcn_wave_barrier();
-    if (g == 0) {
-      dvec[16 * K + c] = p;
-      zq = fma(p, p, zq);
+      for (int s = 0; s < 4; ++s) z = mfma(Wd[s], rk[s], z);
+      rk = z;
+      lds_tile_store(zbuf, K, lane, z);
+    } else {
+      if constexpr (K > 0) {   // d_K -= sum over K' < K of U_K'K^T z_K' (deferred)
+        const double q = xrow_sum((K < C::NW) ? dpA : dpB);
+        if (g == 0) dvec[16 * K + c] -= q;
+        __builtin_amdgcn_wave_barrier();
+      }
+      double p = 0.0;   // z_K = W d_K
+#pragma unroll
+      for (int s = 0; s < 4; ++s) p = fma(Wd[s], dvec[16 * K + 4 * s + g], p);
+      p = xrow_sum(p);
+      __builtin_amdgcn_wave_barrier();
+      if (g == 0) {
+        dvec[16 * K + c] = p;
+        zq = fma(p, p, zq);
+      }
     }
     df_publish(wdone, K + 1, lane_in);
     __builtin_amdgcn_s_setprio(0);
@@ -1708,9 +1722,14 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
     d4 W;
 #pragma unroll
     for (int s = 0; s < 4; ++s) W[s] = Wall[(K * 4 + s) * 64 + lane];
-    double zr[4];
+    double zr[4] = {0.0, 0.0, 0.0, 0.0};
+    d4 zk = (d4){0.0, 0.0, 0.0, 0.0};
+    if constexpr (RP) {
+      zk = lds_tile_load(zbuf, K, lane);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zr[r] = dvec[16 * K + g + 4 * r];
+      for (int r = 0; r < 4; ++r) zr[r] = dvec[16 * K + g + 4 * r];
+    }
     double* rb = (K % 3 == 0) ? row0 : (K % 3 == 1 ? row1 : row2);      // three row buffers: the writer of row K needs row K - 3 dead
     const bool haveA = (K < C::NW) && (JA > K), haveB = JB > K;
     if constexpr (K >= 3) {
@@ -1733,10 +1752,16 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
       for (int s = 0; s < 4; ++s) acc = mfma(W[s], t[s], acc);
       U[sl] = acc;
       lds_tile_store(rb, J, lane, acc);
+      if constexpr (RP) {                       // R_J -= U_KJ^T Z_K (the accumulator tile IS the A operand of its transpose)
+        d4& rj = (h == 0) ? *RAp : *RBp;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {             // d_J -= U_KJ^T z_K (partial sums, see dpA / dpB)
-        if (h == 0) dpA = fma(acc[r], zr[r], dpA);
-        else dpB = fma(acc[r], zr[r], dpB);
+        for (int s = 0; s < 4; ++s) rj = mfma_sub(acc[s], zk[s], rj);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {           // d_J -= U_KJ^T z_K (partial sums, see dpA / dpB)
+          if (h == 0) dpA = fma(acc[r], zr[r], dpA);
+          else dpB = fma(acc[r], zr[r], dpB);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane_in == 0) __hip_atomic_store(&rowpub[J], K + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
