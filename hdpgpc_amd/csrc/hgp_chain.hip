@@ -49,6 +49,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_list(const hgp_gemm_item* _
   const int ti = tile / ntn, tj = tile % ntn;
   const int row = 16 * ti + c, col = 16 * tj + c;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  double dv[4] = {0.0, 0.0, 0.0, 0.0};   // the addend travels with the operands (behind the products it was one more round trip)
+  if (q.D) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * ti + g + 4 * r;
+      if (i < q.M && col < q.N) dv[r] = q.D[(size_t)i * q.ldd + col];
+    }
+  }
   const int nk = (q.K + 3) >> 2;
   constexpr int TRIP = 24;               // K <= 96 in one trip: all operand loads are in flight before the first MFMA
   for (int k0 = 0; k0 < nk; k0 += TRIP) {
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_list(const hgp_gemm_item* _
     const int i = 16 * ti + g + 4 * r;
     if (i < q.M && col < q.N) {
       double v = q.alpha * acc[r];
-      if (q.D) v += q.beta * q.D[(size_t)i * q.ldd + col];
+      if (q.D) v += q.beta * dv[r];
       if (q.add_eye && i == col) v += q.add_eye;
       q.C[(size_t)i * q.ldc + col] = v;
       if (q.C2) q.C2[(size_t)i * q.ldc + col] = v;
