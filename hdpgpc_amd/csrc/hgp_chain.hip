@@ -228,56 +228,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_inv_rhs(InvRhsArgs a) {
   }
 }
 
-// ... and with the DATAFLOW factorisation (cooph_factor_df<NB, true>, NB / 2 waves per workgroup, NB = the even number of 16-blocks:
+// ... and with the DATAFLOW factorisation (cooph_factor_df<NB, 1>, NB / 2 waves per workgroup, NB = the even number of 16-blocks:
 // no padding at T = 90): no workgroup barrier inside the factorisation - the wave that owns block K + 1 solves only that panel tile,
 // updates its diagonal tile from the accumulator, factors it and publishes W_{K+1} and Z_{K+1} while the others are still in the
 // trailing update of step K.  The barrier version above spends 4.5 us per block step for 1.2 us of diag16_acc.
-template <int NB>
-__device__ __forceinline__ void cooph_load_sym_upper(d4 (&U)[CoopH<NB>::NT], const double* __restrict__ A, int ld, int n, int wave,
-                                                     int lane_in, double* scr_w) {
-  using C = CoopH<NB>;
-  // my block columns JA = wave (tiles I <= JA in slotA(I)) and JB = NB - 1 - wave (slotB(I)); both triangles are read as they lie
-  // (coalesced rows) and the lower one is transposed through a per-wave 16 x 18 LDS tile: U = 0.5 (A + A^T), identity padding
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int lane = launder(lane_in);
-    const int g = lane >> 4, c = lane & 15;
-    const int J = h == 0 ? wave : NB - 1 - wave;
-    d4 nat[NB], trn[NB];
-#pragma unroll
-    for (int I = 0; I < NB; ++I) {
-      if (h == 0 && I >= C::NW) continue;           // column A only reaches block rows < NW
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * I + g + 4 * r, j = 16 * J + c;          // natural element of tile (I, J)
-        nat[I][r] = (I <= J && i < n && j < n) ? A[(size_t)i * ld + j] : 0.0;
-        const int i2 = 16 * J + g + 4 * r, j2 = 16 * I + c;        // natural element of tile (J, I)
-        trn[I][r] = (I < J && i2 < n && j2 < n) ? A[(size_t)i2 * ld + j2] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int I = 0; I < NB; ++I) {
-      if (h == 0 && I >= C::NW) continue;
-      const d4 src = (I == J) ? nat[I] : trn[I];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) scr_w[(g + 4 * r) * DIAG_LD + c] = src[r];
-      __builtin_amdgcn_wave_barrier();
-      d4 v = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * I + g + 4 * r, j = 16 * J + c;
-        const double t = scr_w[c * DIAG_LD + g + 4 * r];
-        double x = 0.5 * (nat[I][r] + t);
-        if (!(i < n && j < n)) x = (i == j) ? 1.0 : 0.0;
-        if (I <= J) v[r] = x;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (h == 0) U[C::slotA(I < C::NW ? I : 0)] = (I <= J) ? v : U[C::slotA(I < C::NW ? I : 0)];
-      else if (I <= J) U[C::slotB(I)] = v;
-    }
-  }
-}
-
 template <int NB>
 __global__ __launch_bounds__(64 * CoopH<NB>::NW) void k_cooph_inv_rhs(InvRhsArgs a) {
   using C = CoopH<NB>;
@@ -328,7 +282,7 @@ __global__ __launch_bounds__(64 * CoopH<NB>::NW) void k_cooph_inv_rhs(InvRhsArgs
   }
   PivotAcc pa;
   pa.init();
-  cooph_factor_df<NB, true>(U, row0, row0 + NB * 256, row0 + 2 * NB * 256, Wall, scr, flags, wave, lane, pa, T, nullptr, &RA, &RB, zbuf);
+  cooph_factor_df<NB, 1>(U, row0, row0 + NB * 256, row0 + 2 * NB * 256, Wall, scr, flags, wave, lane, pa, T, nullptr, &RA, &RB, zbuf);
   double* Z = (is_rhs ? a.rhs_out : a.Linv) + (size_t)m * T * T;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {

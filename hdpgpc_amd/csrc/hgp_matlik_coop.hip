@@ -113,33 +113,81 @@ __device__ __forceinline__ void solve_panels(const double* __restrict__ Lp, cons
   }
 }
 
-template <int NB>
-__global__ __launch_bounds__(64 * WAVES) void k_coop_mniw(MniwCoopArgs a) {
-  using C = Coop<NB>;
+// Which factorisation the two kernels run on (round 4, last session): DF = the eight-wave (NB / 2) dataflow factorisation of the
+// pair kernels with a packed output (cooph_factor_df<NB, 2>) instead of the four-wave barrier version - the factor was 146 of the
+// 385 / 515 us of a call, and the panel solves behind it are spread over twice the waves.  HGP_MATLIK_COOP4=1 keeps the four-wave kernels.
+template <int NB, bool DF>
+struct MatlikLds {
+  static constexpr int NWK = DF ? CoopH<NB>::NW : WAVES;
+  // DF: three row buffers + W of every block + per-wave diag16 scratch + red[16] + flags;  else Coop<NB>'s layout
+  static constexpr int DOUBLES = DF ? (4 * NB * 256 + NWK * DIAG_SCR + 16 + (16 + NB + 16) / 2 + 2) : Coop<NB>::LDS_DOUBLES;
+};
+
+// factor 0.5 (S + S^T) + shift into the packed workspace; returns info (first bad pivot or 0) in every thread
+template <int NB, bool DF>
+__device__ __forceinline__ int matlik_factor(const double* __restrict__ S, int T, double add, double jitter_rel, double* smem, int wave,
+                                             int lane, double* Lp, double* Wp) {
+  int info = 0;
+  if constexpr (DF) {
+    using C = CoopH<NB>;
+    double* row0 = smem;
+    double* Wall = row0 + 3 * NB * 256;
+    double* scr = Wall + NB * 256 + wave * DIAG_SCR;
+    double* red = Wall + NB * 256 + C::NW * DIAG_SCR;
+    int* flags = reinterpret_cast<int*>(red + 16);
+    d4 U[C::NT];
+#pragma unroll
+    for (int i_ = 0; i_ < C::NT; ++i_) U[i_] = (d4){0.0, 0.0, 0.0, 0.0};
+    cooph_load_sym_upper<NB>(U, S, T, T, wave, lane, scr);
+    double sh = add;
+    if (jitter_rel != 0.0) sh += jitter_rel * fmax(cooph_diag_abs_mean<NB>(U, T, wave, lane, 0.0, red), F64_EPS);
+    if (sh != 0.0) cooph_add_diag<NB>(U, sh, T, wave, lane);
+    PivotAcc pa;
+    pa.init();
+    cooph_factor_df<NB, 2>(U, row0, row0 + NB * 256, row0 + 2 * NB * 256, Wall, scr, flags, wave, lane, pa, T, nullptr, nullptr, nullptr,
+                           nullptr, Lp, Wp);
+    int* redi = flags + 16 + NB;
+    if (lane == 0) redi[wave] = pa.info;
+    __syncthreads();
+    for (int w = 0; w < C::NW; ++w)
+      if (redi[w] != 0 && (info == 0 || redi[w] < info)) info = redi[w];
+    __syncthreads();
+  } else {
+    using C = Coop<NB>;
+    double* rowbuf = smem;
+    double* Rbuf = rowbuf + NB * 256;
+    double* Wbuf = Rbuf + NB * 256;
+    double* scr = Wbuf + 256;
+    double* red = scr + DIAG_SCR;
+    int* redi = reinterpret_cast<int*>(red + 8);
+    d4 U[C::NT];
+    coop_load_sym_upper<NB>(U, S, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
+    __syncthreads();   // rowbuf served as per-wave staging for the loader
+    double sh = add;
+    if (jitter_rel != 0.0) sh += jitter_rel * fmax(coop_diag_abs_mean<NB>(U, T, wave, lane, 0.0, red), F64_EPS);
+    if (sh != 0.0) coop_add_diag<NB>(U, sh, T, wave, lane);
+    __syncthreads();
+    PivotAcc pa;
+    pa.init();
+    coop_factor<NB, 0>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T, nullptr, nullptr, 0, Lp, Wp);
+    (void)coop_logdet_info(pa, wave, lane, red, redi, info);
+  }
+  return info;
+}
+
+template <int NB, bool DF>
+__global__ __launch_bounds__((64 * MatlikLds<NB, DF>::NWK)) void k_coop_mniw(MniwCoopArgs a) {
+  constexpr int NWK = MatlikLds<NB, DF>::NWK;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* rowbuf = smem;
-  double* Rbuf = rowbuf + NB * 256;
-  double* Wbuf = Rbuf + NB * 256;
-  double* scr = Wbuf + 256;
-  double* red = scr + DIAG_SCR;
-  int* redi = reinterpret_cast<int*>(red + 8);
+  double* red = smem + MatlikLds<NB, DF>::DOUBLES;   // [NWK] partial sums (behind whatever the factorisation uses)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int m = blockIdx.x;
   const int T = a.T;
   const long tt = (long)T * T;
   double* Lp = a.ws + (size_t)m * packed_doubles<NB>();
   double* Wp = Lp + (size_t)(NB * (NB - 1) / 2) * 256;
-  int info;
-  {
-    d4 U[C::NT];
-    coop_load_sym_upper<NB>(U, a.Sigma + (size_t)m * tt, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
-    __syncthreads();   // rowbuf served as per-wave staging for the loader
-    coop_add_diag<NB>(U, 1e-8, T, wave, lane);        // chol(0.5 (S + S^T) + 1e-8 I), GPI_model.py:1353
-    PivotAcc pa;
-    pa.init();
-    coop_factor<NB, 0>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T, nullptr, nullptr, 0, Lp, Wp);
-    (void)coop_logdet_info(pa, wave, lane, red, redi, info);
-  }
+  // chol(0.5 (S + S^T) + 1e-8 I), GPI_model.py:1353
+  const int info = matlik_factor<NB, DF>(a.Sigma + (size_t)m * tt, T, 1e-8, 0.0, smem, wave, lane, Lp, Wp);
   __threadfence();     // the packed factor is read back through L2 by all four waves
   __syncthreads();
   const int nb = (T + 15) >> 4;
@@ -147,11 +195,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_mniw(MniwCoopArgs a) {
   const double* Mm = a.M + (size_t)m * tt;
   const double* mean = a.m_mean + (size_t)m * a.prior_stride;
   const double* scale = a.scale + (size_t)m * a.prior_stride;
-  constexpr int PAN = 2;     // panels solved side by side by a wave (the spills of the NB = 16 instance are the factorisation's, as in k_coop_potrf<16>)
+  constexpr int PAN = DF ? 1 : 2;     // panels solved side by side by a wave (eight waves: 256 registers each, one panel) (the spills of the NB = 16 instance are the factorisation's, as in k_coop_potrf<16>)
   const int ngrp = (nb + PAN - 1) / PAN;
   double acc = 0.0;
   // D panels: groups w, w + 4, ...
-  for (int pp = wave; pp < ngrp; pp += WAVES) {
+  for (int pp = wave; pp < ngrp; pp += NWK) {
     const int J0 = PAN * pp;
     auto rhs = [&](int K, int p) {
       d4 v;
@@ -172,8 +220,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_mniw(MniwCoopArgs a) {
     solve_panels<NB, PAN>(Lp, Wp, nb, 0, lane, rhs, done);
   }
   // identity panels: sum_j S_jj |L^-1 e_j|^2; panel J costs (nb - J)^2 / 2 tile products: groups dealt in snake order
-  for (int t = 0; t < (ngrp + WAVES - 1) / WAVES; ++t) {
-    const int pp = (t & 1) ? (t + 1) * WAVES - 1 - wave : t * WAVES + wave;
+  for (int t = 0; t < (ngrp + NWK - 1) / NWK; ++t) {
+    const int pp = (t & 1) ? (t + 1) * NWK - 1 - wave : t * NWK + wave;
     if (pp >= ngrp) continue;
     const int J0 = PAN * pp;
     double sj[PAN];
@@ -200,18 +248,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_mniw(MniwCoopArgs a) {
   if (lane == 0) red[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    for (int w = 4; w < NWK; ++w) tot += red[w];
     a.out[m] = (info != 0) ? __builtin_nan("") : -0.5 * tot;
     if (a.info) a.info[m] = info;
   }
 }
 
+template <int NB, bool DF>
+int launch_coop_mniw_v(const MniwCoopArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(double) * (MatlikLds<NB, DF>::DOUBLES + 8);
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_mniw<NB, DF>), lds)) return rc_;
+  hipLaunchKernelGGL((k_coop_mniw<NB, DF>), dim3(a.b), dim3(64 * MatlikLds<NB, DF>::NWK), lds, st, a);
+  return launch_status();
+}
 template <int NB>
 int launch_coop_mniw(const MniwCoopArgs& a, hipStream_t st) {
-  const size_t lds = sizeof(double) * Coop<NB>::LDS_DOUBLES;
-  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_mniw<NB>), lds)) return rc_;
-  hipLaunchKernelGGL(k_coop_mniw<NB>, dim3(a.b), dim3(64 * WAVES), lds, st, a);
-  return launch_status();
+  static const bool four = env_on("HGP_MATLIK_COOP4");
+  return four ? launch_coop_mniw_v<NB, false>(a, st) : launch_coop_mniw_v<NB, true>(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------ a8
@@ -230,17 +284,13 @@ struct LatCoopArgs {
 template <int NB>
 constexpr size_t lat_ws_doubles() { return packed_doubles<NB>() + (size_t)NB * NB * 256; }
 
-template <int NB>
-__global__ __launch_bounds__(64 * WAVES) void k_coop_lat(LatCoopArgs a) {
-  using C = Coop<NB>;
+template <int NB, bool DF>
+__global__ __launch_bounds__((64 * MatlikLds<NB, DF>::NWK)) void k_coop_lat(LatCoopArgs a) {
+  constexpr int NWK = MatlikLds<NB, DF>::NWK;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* rowbuf = smem;
-  double* Rbuf = rowbuf + NB * 256;
-  double* Wbuf = Rbuf + NB * 256;
-  double* scr = Wbuf + 256;
-  double* red = scr + DIAG_SCR;
-  int* redi = reinterpret_cast<int*>(red + 8);
-  double* rvec = smem + C::LDS_DOUBLES;              // [16 NB]: r = f_cur - A f_prev (zero padded)
+  double* red = smem + MatlikLds<NB, DF>::DOUBLES;   // [NWK] partial sums
+  double* rvec = red + 8;                            // [16 NB]: r = f_cur - A f_prev (zero padded)
+  double* stage = smem + (DF ? 4 * NB * 256 : 0);    // [NWK][DIAG_SCR]: per-wave 16 x 18 staging tiles of the Gram phase (the factorisation's diag16 scratch / row buffer, free by then)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int m = blockIdx.x;
   const int T = a.T;
@@ -257,7 +307,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_lat(LatCoopArgs a) {
     double fpv[NB / 4];
 #pragma unroll
     for (int u = 0; u < NB / 4; ++u) fpv[u] = (64 * u + lane < T) ? fp[64 * u + lane] : 0.0;
-    for (int i = wave; i < 16 * NB; i += WAVES) {
+    for (int i = wave; i < 16 * NB; i += NWK) {
       double sacc = 0.0;
       if (i < T) {
 #pragma unroll
@@ -267,28 +317,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_lat(LatCoopArgs a) {
       if (lane == 0) rvec[i] = (i < T) ? fc[i] - sacc : 0.0;
     }
   }
-  int info;
-  {
-    d4 U[C::NT];
-    coop_load_sym_upper<NB>(U, a.Gamma + (size_t)m * tt, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
-    __syncthreads();   // rowbuf served as per-wave staging for the loader
-    {                  // _chol_spd(Gamma): + 1e-8 max(mean |diag|, eps) I  (GPI_model.py:83-87,312)
-      const double dm = coop_diag_abs_mean<NB>(U, T, wave, lane, 0.0, red);
-      coop_add_diag<NB>(U, 1e-8 * fmax(dm, F64_EPS), T, wave, lane);
-    }
-    __syncthreads();
-    PivotAcc pa;
-    pa.init();
-    coop_factor<NB, 0>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T, nullptr, nullptr, 0, Lp, Wp);
-    (void)coop_logdet_info(pa, wave, lane, red, redi, info);
-  }
+  __syncthreads();   // rvec complete before the factorisation reuses nothing of it, but its barriers must see every wave here
+  // _chol_spd(Gamma): + 1e-8 max(mean |diag|, eps) I  (GPI_model.py:83-87,312)
+  const int info = matlik_factor<NB, DF>(a.Gamma + (size_t)m * tt, T, 0.0, 1e-8, smem, wave, lane, Lp, Wp);
   __threadfence();
   __syncthreads();
-  constexpr int PAN = 2;
+  constexpr int PAN = DF ? 1 : 2;
   const int ngrp = (nb + PAN - 1) / PAN;
   double acc = 0.0;
   // Y = L^-1 A by panel pairs, stored as packed accumulator tiles
-  for (int pp = wave; pp < ngrp; pp += WAVES) {
+  for (int pp = wave; pp < ngrp; pp += NWK) {
     const int J0 = PAN * pp;
     auto rhs = [&](int K, int p) {
       d4 v;
@@ -309,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_lat(LatCoopArgs a) {
     solve_panels<NB, PAN>(Lp, Wp, nb, 0, lane, rhs, done);
   }
   // z = L^-1 r (one more panel, column 0; the wave with the fewest panel pairs takes it)
-  if (wave == (ngrp % WAVES)) {
+  if (wave == (ngrp % NWK)) {
     auto rhs = [&](int K, int) {
       d4 v;
       const int ln = launder(lane);
@@ -331,9 +369,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_lat(LatCoopArgs a) {
     const double* Pm = a.P + (size_t)m * tt;
     const int nb2 = (nb + 1) >> 1;
     const int nblk = nb2 * (nb2 + 1) / 2;
-    double* scw = scr;                               // this wave's 16 x 18 staging tile (transposes of P)
-    scw = rowbuf + wave * DIAG_SCR;
-    for (int t = wave; t < nblk; t += WAVES) {
+    double* scw = stage + wave * DIAG_SCR;           // this wave's 16 x 18 staging tile (transposes of P)
+    for (int t = wave; t < nblk; t += NWK) {
       int Ib = 0, rem = t;                           // block (Ib, Jb), Ib <= Jb, row-major over the upper triangle
       while (rem >= nb2 - Ib) {
         rem -= nb2 - Ib;
@@ -403,18 +440,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_coop_lat(LatCoopArgs a) {
   if (lane == 0) red[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    for (int w = 4; w < NWK; ++w) tot += red[w];
     a.out[m] = (info != 0) ? __builtin_nan("") : -0.5 * tot;
     if (a.info) a.info[m] = info;
   }
 }
 
+template <int NB, bool DF>
+int launch_coop_lat_v(const LatCoopArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(double) * (MatlikLds<NB, DF>::DOUBLES + 8 + 16 * NB);
+  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_lat<NB, DF>), lds)) return rc_;
+  hipLaunchKernelGGL((k_coop_lat<NB, DF>), dim3(a.b), dim3(64 * MatlikLds<NB, DF>::NWK), lds, st, a);
+  return launch_status();
+}
 template <int NB>
 int launch_coop_lat(const LatCoopArgs& a, hipStream_t st) {
-  const size_t lds = sizeof(double) * (Coop<NB>::LDS_DOUBLES + 16 * NB);
-  if (int rc_ = hgp_internal_ensure_dynamic_lds(reinterpret_cast<const void*>(&k_coop_lat<NB>), lds)) return rc_;
-  hipLaunchKernelGGL(k_coop_lat<NB>, dim3(a.b), dim3(64 * WAVES), lds, st, a);
-  return launch_status();
+  static const bool four = env_on("HGP_MATLIK_COOP4");
+  return four ? launch_coop_lat_v<NB, false>(a, st) : launch_coop_lat_v<NB, true>(a, st);
 }
 
 }  // namespace

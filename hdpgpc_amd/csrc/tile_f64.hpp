@@ -1493,6 +1493,54 @@ __device__ __forceinline__ void cooph_add_diag(d4 (&U)[CoopH<NB>::NT], double sh
   }
 }
 
+// 0.5 (A + A^T) of a row-major [n, ld] matrix into the CoopH tile layout of this wave (identity padding); scr_w: a 16 x 18 LDS
+// staging tile private to the wave
+template <int NB>
+__device__ __forceinline__ void cooph_load_sym_upper(d4 (&U)[CoopH<NB>::NT], const double* __restrict__ A, int ld, int n, int wave,
+                                                     int lane_in, double* scr_w) {
+  using C = CoopH<NB>;
+  // my block columns JA = wave (tiles I <= JA in slotA(I)) and JB = NB - 1 - wave (slotB(I)); both triangles are read as they lie
+  // (coalesced rows) and the lower one is transposed through a per-wave 16 x 18 LDS tile: U = 0.5 (A + A^T), identity padding
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int lane = launder(lane_in);
+    const int g = lane >> 4, c = lane & 15;
+    const int J = h == 0 ? wave : NB - 1 - wave;
+    d4 nat[NB], trn[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      if (h == 0 && I >= C::NW) continue;           // column A only reaches block rows < NW
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;          // natural element of tile (I, J)
+        nat[I][r] = (I <= J && i < n && j < n) ? A[(size_t)i * ld + j] : 0.0;
+        const int i2 = 16 * J + g + 4 * r, j2 = 16 * I + c;        // natural element of tile (J, I)
+        trn[I][r] = (I < J && i2 < n && j2 < n) ? A[(size_t)i2 * ld + j2] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      if (h == 0 && I >= C::NW) continue;
+      const d4 src = (I == J) ? nat[I] : trn[I];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scr_w[(g + 4 * r) * DIAG_LD + c] = src[r];
+      __builtin_amdgcn_wave_barrier();
+      d4 v = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + g + 4 * r, j = 16 * J + c;
+        const double t = scr_w[c * DIAG_LD + g + 4 * r];
+        double x = 0.5 * (nat[I][r] + t);
+        if (!(i < n && j < n)) x = (i == j) ? 1.0 : 0.0;
+        if (I <= J) v[r] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (h == 0) U[C::slotA(I < C::NW ? I : 0)] = (I <= J) ? v : U[C::slotA(I < C::NW ? I : 0)];
+      else if (I <= J) U[C::slotB(I)] = v;
+    }
+  }
+}
+
 // Factor + eliminate the single right-hand side dvec (on exit z = L^{-1} d); returns this wave's share of z^T z.
 template <int NB>
 __device__ __forceinline__ double cooph_factor(d4 (&U)[CoopH<NB>::NT], double* rowbuf, double* Wbuf, double* scr, int wave,
@@ -1651,10 +1699,15 @@ __device__ __forceinline__ void df_wait_all_ge(int* tdone, int v, int lane, int*
 // of the member step, k_cooph_inv_rhs).  Tile I of it lives in the registers of the wave that owns block column I (*RAp for its column
 // JA, *RBp for JB); Z_K = W_K R_K is formed by the pivot wave right behind diag16_acc and published in zbuf ([NB] tiles of LDS)
 // together with W_K; R_J -= U_KJ^T Z_K follows each panel tile while it is still in its accumulator.  On exit the tiles hold L^-1 R.
-template <int NB, bool RP = false>
+// RHS = 2: no right-hand side at all (a8 / a9 above T = 128: the factor is wanted, packed).  Lpack / Wpack (optional, any mode): the
+// factor in MFMA OPERAND order for a consumer that streams it, as coop_factor writes it - tile U_KJ (K < J) at index J (J - 1) / 2 + K
+// of Lpack, W_K at index K of Wpack, 32 bytes per lane.
+template <int NB, int RHS = 0>
 __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double* row0, double* row1, double* row2, double* Wall,
                                                   double* scr, int* flags, int wave, int lane_in, PivotAcc& pa, int n, double* dvec,
-                                                  d4* RAp = nullptr, d4* RBp = nullptr, double* zbuf = nullptr) {
+                                                  d4* RAp = nullptr, d4* RBp = nullptr, double* zbuf = nullptr,
+                                                  double* Lpack = nullptr, double* Wpack = nullptr) {
+  constexpr bool RP = (RHS == 1), NORHS = (RHS == 2);
   using C = CoopH<NB>;
   int* wdone = flags;
   int* tdone = flags + 1;        // [8]
@@ -1684,7 +1737,9 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
     const d4 Wd = diag16_sel<false>(U[C::diag_slot(K)], scr, lane, pa, 16 * K, nullptr, 0, n - 16 * K);
 #pragma unroll
     for (int s = 0; s < 4; ++s) Wall[(K * 4 + s) * 64 + lane] = Wd[s];
-    if constexpr (RP) {      // Z_K = W R_K
+    if (Wpack != nullptr) *reinterpret_cast<d4*>(Wpack + ((size_t)K * 64 + lane) * 4) = Wd;
+    if constexpr (NORHS) {
+    } else if constexpr (RP) {      // Z_K = W R_K
       d4& rk = (K < C::NW) ? *RAp : *RBp;
       d4 z = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1724,7 +1779,8 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
     for (int s = 0; s < 4; ++s) W[s] = Wall[(K * 4 + s) * 64 + lane];
     double zr[4] = {0.0, 0.0, 0.0, 0.0};
     d4 zk = (d4){0.0, 0.0, 0.0, 0.0};
-    if constexpr (RP) {
+    if constexpr (NORHS) {
+    } else if constexpr (RP) {
       zk = lds_tile_load(zbuf, K, lane);
     } else {
 #pragma unroll
@@ -1752,7 +1808,9 @@ __device__ __forceinline__ double cooph_factor_df(d4 (&U)[CoopH<NB>::NT], double
       for (int s = 0; s < 4; ++s) acc = mfma(W[s], t[s], acc);
       U[sl] = acc;
       lds_tile_store(rb, J, lane, acc);
-      if constexpr (RP) {                       // R_J -= U_KJ^T Z_K (the accumulator tile IS the A operand of its transpose)
+      if (Lpack != nullptr) *reinterpret_cast<d4*>(Lpack + ((size_t)(J * (J - 1) / 2 + K) * 64 + lane) * 4) = acc;
+      if constexpr (NORHS) {
+      } else if constexpr (RP) {                // R_J -= U_KJ^T Z_K (the accumulator tile IS the A operand of its transpose)
         d4& rj = (h == 0) ? *RAp : *RBp;
 #pragma unroll
         for (int s = 0; s < 4; ++s) rj = mfma_sub(acc[s], zk[s], rj);
