@@ -21,7 +21,8 @@ $(LIB): $(OBJS)
 
 # diagnostic build with in-kernel cycle stamps (tools/stamps.py); never used by the product path
 stamps: $(SRCS) $(HDR)
-	$(HIPCC) $(FLAGS) -DHGP_STAMPS -shared -o hdpgpc_amd/lib/libhdpgpc_hip_stamps.so $(SRCS)
+	mkdir -p hdpgpc_amd/lib/ab
+	$(HIPCC) $(FLAGS) -DHGP_STAMPS -shared -o hdpgpc_amd/lib/ab/libhgp_stamps.so $(SRCS)
 
 # diagnostic builds for the cooperative-factor race (tile_f64.hpp, coop_factor): a delay injected in front of the
 # right-hand-side row update, with the pre-round-2 round-robin dealing (races) and with the owner dealing (immune)

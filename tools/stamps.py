@@ -2,7 +2,7 @@
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("HGP_LIB", os.path.join(ROOT, "hdpgpc_amd", "lib", "libhdpgpc_hip_stamps.so"))
+os.environ.setdefault("HGP_LIB", os.path.join(ROOT, "hdpgpc_amd", "lib", "ab", "libhgp_stamps.so"))
 import hdpgpc_amd._ffi as ffi
 import numpy as np, torch
 from hdpgpc_amd import ops
