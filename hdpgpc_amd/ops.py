@@ -566,7 +566,9 @@ class GemmList:
         host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
         self._dev = host.to(self.device)
         self._map = None
-        if 8 < len(self._items) <= 65535:   # long lists: per-tile map instead of the per-wave walk (16-bit item index; longer lists walk)
+        # per-tile map instead of the per-wave walk over the list (one dependent load per item: 7.8 vs 6.9 us for a 5-item level of one
+        # chain under rocprofv3, tools/time_gemm_list.py); 16-bit item index, longer lists walk
+        if 1 < len(self._items) <= 65535:
             m = np.concatenate([(i << 16) | np.arange(n, dtype=np.uint32) for i, n in enumerate(self._item_tiles)]).astype(np.uint32)
             self._map = torch.from_numpy(m.view(np.int32)).to(self.device)
             self._cum = np.concatenate([[0], np.cumsum(self._item_tiles)])
@@ -575,6 +577,10 @@ class GemmList:
     def run(self):
         if self._dev is None:
             self.finalize()
+        if self._map is not None:
+            _ffi.check(_ffi.lib.hgp_gemm_list_mapped_f64(_ptr(self._dev), len(self._items), _ptr(self._map), self.tiles, _stream()),
+                       "gemm_list_mapped")
+            return
         _ffi.check(_ffi.lib.hgp_gemm_list_f64(_ptr(self._dev), len(self._items), self.tiles, _stream()), "gemm_list")
 
     def run_range(self, first, count):
