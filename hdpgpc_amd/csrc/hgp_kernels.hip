@@ -1265,6 +1265,7 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = a.T;
   const long tt = (long)T * T;
+  const int kpad = (T + 3) & ~3;          // k-steps beyond T multiply the zero padding
   for (int i = tid; i < 96 * PITCH; i += 64 * RTS_WAVES) {   // zero padding once (rows/cols >= T are never written below)
     Jl[i] = 0.0;
     Dl[i] = 0.0;
@@ -1273,11 +1274,11 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
     vl[tid] = 0.0;
     ml[tid] = (tid < T) ? a.M[(size_t)(a.n - 1) * T + tid] : 0.0;
   }
-  // tile (I, Jc) = wave + 12 i of a row-major [T,T] matrix, accumulator layout, zero outside
+  // my tiles (I, Jc) = (wave / 2, 3 (wave % 2) + i), i = 0 .. 2, of a row-major [T,T] matrix, accumulator layout, zero outside
   auto load_tiles = [&](const double* __restrict__ X, d4 (&v)[3]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
+      const int I = wave >> 1, Jc = 3 * (wave & 1) + i;   // my three tiles share block row I (one A operand per k-step for three MFMAs)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * I + g + 4 * r, col = 16 * Jc + c;
@@ -1325,7 +1326,7 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
+      const int I = wave >> 1, Jc = 3 * (wave & 1) + i;   // my three tiles share block row I (one A operand per k-step for three MFMAs)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Dl[(16 * I + g + 4 * r) * PITCH + 16 * Jc + c] = cn[i][r] - pt[i][r];
     }
@@ -1343,13 +1344,16 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
     }
     // ---- X = J D
     d4 X[3];
+    {
+      const int I = wave >> 1, J0 = 3 * (wave & 1);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-      for (int k = 0; k < 96; k += 4) acc = mfma(Jl[(16 * I + c) * PITCH + k + g], Dl[(k + g) * PITCH + 16 * Jc + c], acc);
-      X[i] = acc;
+      for (int i = 0; i < 3; ++i) X[i] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+      for (int k = 0; k < kpad; k += 4) {
+        const double av = Jl[(16 * I + c) * PITCH + k + g];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) X[i] = mfma(av, Dl[(k + g) * PITCH + 16 * (J0 + i) + c], X[i]);
+      }
     }
     // ---- m_t += J v : eight lanes per row, 12 columns each, summed inside the 8-lane group
     double mnew = 0.0;
@@ -1366,7 +1370,7 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
     __syncthreads();                         // every wave has finished reading D, v and m_{t+1}
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
+      const int I = wave >> 1, Jc = 3 * (wave & 1) + i;   // my three tiles share block row I (one A operand per k-step for three MFMAs)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Dl[(16 * I + g + 4 * r) * PITCH + 16 * Jc + c] = X[i][r];
     }
@@ -1379,17 +1383,23 @@ __global__ __launch_bounds__(64 * RTS_WAVES) void k_rts_chain(RtsArgs a) {
     }
     // ---- C_t = (filtered C_t) + X J^T : the result stays in cn for the next step
     double* Ct = a.Cv + (size_t)t * tt;
+    {
+      const int I = wave >> 1, J0 = 3 * (wave & 1);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int tile = wave + RTS_WAVES * i, I = tile / NBR, Jc = tile % NBR;
-      d4 acc = ct[i];
-#pragma unroll 4
-      for (int k = 0; k < 96; k += 4) acc = mfma(Dl[(16 * I + c) * PITCH + k + g], Jl[(16 * Jc + c) * PITCH + k + g], acc);
-      cn[i] = acc;
+      for (int i = 0; i < 3; ++i) cn[i] = ct[i];
+#pragma unroll 8
+      for (int k = 0; k < kpad; k += 4) {
+        const double av = Dl[(16 * I + c) * PITCH + k + g];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + g + 4 * r, col = 16 * Jc + c;
-        if (row < T && col < T) Ct[(size_t)row * T + col] = acc[r];
+        for (int i = 0; i < 3; ++i) cn[i] = mfma(av, Jl[(16 * (J0 + i) + c) * PITCH + k + g], cn[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + g + 4 * r, col = 16 * (J0 + i) + c;
+          if (row < T && col < T) Ct[(size_t)row * T + col] = cn[i][r];
+        }
       }
     }
     if (t > 0) load_tiles(a.Cv + (size_t)(t - 1) * tt, ct);          // consumed one whole step later
