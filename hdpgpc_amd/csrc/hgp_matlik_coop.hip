@@ -456,8 +456,10 @@ int launch_coop_lat_v(const LatCoopArgs& a, hipStream_t st) {
 }
 template <int NB>
 int launch_coop_lat(const LatCoopArgs& a, hipStream_t st) {
+  // the eight-wave form is the faster CALL (281 vs 341 us for a few items); with a workgroup on every CU the four-wave form's larger
+  // register budget wins for a8 (0.515 vs 0.543 ms per 256 items at T = 256)
   static const bool four = env_on("HGP_MATLIK_COOP4");
-  return four ? launch_coop_lat_v<NB, false>(a, st) : launch_coop_lat_v<NB, true>(a, st);
+  return (four || a.b >= 200) ? launch_coop_lat_v<NB, false>(a, st) : launch_coop_lat_v<NB, true>(a, st);
 }
 
 }  // namespace
