@@ -317,9 +317,32 @@ __global__ __launch_bounds__((64 * MatlikLds<NB, DF>::NWK)) void k_coop_lat(LatC
       if (lane == 0) rvec[i] = (i < T) ? fc[i] - sacc : 0.0;
     }
   }
-  __syncthreads();   // rvec complete before the factorisation reuses nothing of it, but its barriers must see every wave here
+  // (no barrier here: r is consumed behind the factorisation's barriers, and the waves that finish their rows of r early start on Gamma)
   // _chol_spd(Gamma): + 1e-8 max(mean |diag|, eps) I  (GPI_model.py:83-87,312)
-  const int info = matlik_factor<NB, DF>(a.Gamma + (size_t)m * tt, T, 0.0, 1e-8, smem, wave, lane, Lp, Wp);
+  int info;
+  if constexpr (DF) {
+    info = matlik_factor<NB, true>(a.Gamma + (size_t)m * tt, T, 0.0, 1e-8, smem, wave, lane, Lp, Wp);
+  } else {   // (written out: through the helper the NB = 16 instance compiles 8 % slower - 0.54 vs 0.50 ms per 256 items)
+    using C = Coop<NB>;
+    double* rowbuf = smem;
+    double* Rbuf = rowbuf + NB * 256;
+    double* Wbuf = Rbuf + NB * 256;
+    double* scr = Wbuf + 256;
+    double* redf = scr + DIAG_SCR;
+    int* redi = reinterpret_cast<int*>(redf + 8);
+    d4 U[C::NT];
+    coop_load_sym_upper<NB>(U, a.Gamma + (size_t)m * tt, T, T, wave, lane, rowbuf + wave * DIAG_SCR);
+    __syncthreads();   // rowbuf served as per-wave staging for the loader
+    {
+      const double dm = coop_diag_abs_mean<NB>(U, T, wave, lane, 0.0, redf);
+      coop_add_diag<NB>(U, 1e-8 * fmax(dm, F64_EPS), T, wave, lane);
+    }
+    __syncthreads();
+    PivotAcc pa;
+    pa.init();
+    coop_factor<NB, 0>(U, rowbuf, Rbuf, Wbuf, scr, wave, lane, pa, nullptr, 0, T, nullptr, nullptr, 0, Lp, Wp);
+    (void)coop_logdet_info(pa, wave, lane, redf, redi, info);
+  }
   __threadfence();
   __syncthreads();
   constexpr int PAN = DF ? 1 : 2;
