@@ -29,3 +29,27 @@ def test_rho_omega_and_theta_match_the_reference(fixture):
                                                           trans_alpha, kappa, rho, omega)
     assert np.allclose(tt, g["transTheta"], rtol=1e-9) and np.allclose(st, g["startTheta"], rtol=1e-9)
     assert np.allclose(rho, g["rho"], rtol=1e-9) and np.allclose(omega, g["omega"], rtol=1e-9)
+
+
+def test_lean_lbfgsb_driver_is_scipys_fmin_l_bfgs_b_bit_for_bit():
+    """hdp_global._fmin_l_bfgs_b calls the same L-BFGS-B routine with the same arguments as scipy.optimize.fmin_l_bfgs_b (no bounds,
+    fun returns (f, g)): iterates, value, evaluation and iteration counts and the warning flag must be identical."""
+    import scipy.optimize
+    from hdpgpc_amd import hdp_global as H
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        K = int(rng.integers(2, 30))
+        a, b = rng.uniform(0.5, 3, K), rng.normal(size=K)
+        Q = rng.normal(size=(K, K))
+        Q = Q @ Q.T / K + np.eye(K)
+
+        def fun(c):
+            e = np.exp(0.3 * c)
+            return 0.5 * c @ Q @ c + b @ c + a @ e + np.sum(np.log1p(c * c)), Q @ c + b + 0.3 * a * e + 2 * c / (1 + c * c)
+
+        x0 = rng.normal(size=K)
+        for factr in (1e5, 1e7, 1e10):
+            x1, f1, d1 = scipy.optimize.fmin_l_bfgs_b(fun, x0, factr=factr)
+            x2, f2, d2 = H._fmin_l_bfgs_b(fun, x0, factr)
+            assert np.array_equal(x1, x2) and f1 == f2
+            assert (d1["warnflag"], d1["funcalls"], d1["nit"]) == (d2["warnflag"], d2["funcalls"], d2["nit"])
