@@ -79,12 +79,13 @@ def _dev64(t, name):
 
 def raise_on_info(info, what):
     """Mirror torch.linalg.cholesky's error behaviour from a per-item LAPACK info tensor (host sync)."""
-    bad = torch.nonzero(info)
+    host = info.reshape(-1).cpu()          # one copy (torch.nonzero on the device is three launches and a sync: 0.3 ms)
+    bad = torch.nonzero(host)
     if bad.numel():
         i = int(bad[0, 0])
         raise torch.linalg.LinAlgError(
             f"{what}: (Batch element {i}): The factorization could not be completed because the input is not "
-            f"positive-definite (the leading minor of order {int(info.flatten()[i])} is not positive-definite).")
+            f"positive-definite (the leading minor of order {int(host[i])} is not positive-definite).")
 
 
 def gram_rbf(x, y, c, ell, noise=0.0):
